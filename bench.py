@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the particle-robot update loop on MI355X.
+
+Workload (BASELINE.json configs[2]): 10^6 oscillating bots on a hexagonal
+lattice (spacing 2*min_radius) in the generalised arena (2048^2 grid, walls +-240), one light at
+(-230, 0), phase_std 0, dt 0.01, sort_interval 180.  A "step" is one timestep of the whole arena:
+radius actuation + integration + neighbour forces + friction for every bot (one fused kernel).
+State is resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--bots B]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path does not shard a single
+arena (neighbour forces couple every cell each step), so every rank runs its own independent arena
+-- an ensemble member with its own seed offset -- with no collective in the
+timed region; rank 0 gathers the per-arena centroid summaries over RCCL afterwards.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALG_BYTES_PER_PARTICLE_STEP = 64.0  # read 36 + write 28
+HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def hex_lattice(n, spacing):
+    """The initHexGrid recipe (particlebot.cpp:438-481) in float32, vectorised per ring."""
+    import numpy as np
+    f = np.float32
+    h = f(np.sqrt(f(3.0)) * f(0.5))  # powf(3,0.5f)*0.5f
+    ux = np.array([1.0, 0.5, -0.5, -1.0, -0.5, 0.5, 1.0], dtype=f)
+    uy = np.array([0.0, h, h, 0.0, -h, -h, 0.0], dtype=f)
+    pos = np.zeros((n, 2), dtype=f)
+    i, ring, sp = 1, 1, f(spacing)
+    while i < n:
+        j = np.arange(ring, dtype=np.int32)
+        for k in range(6):
+            if i >= n:
+                break
+            a = (ux[k] * (ring - j).astype(f)).astype(f) * sp
+            b = (ux[k + 1] * sp).astype(f) * j.astype(f)
+            x = (a + b).astype(f)
+            a = (uy[k] * (ring - j).astype(f)).astype(f) * sp
+            b = (uy[k + 1] * sp).astype(f) * j.astype(f)
+            y = (a + b).astype(f)
+            m = min(ring, n - i)
+            pos[i:i + m, 0] = x[:m]
+            pos[i:i + m, 1] = y[:m]
+            i += m
+        ring += 1
+    return pos
+
+
+def workload_params(n_bots, seed):
+    """SimParams of the synthetic phototaxis arena (main.cpp defaults + overrides)."""
+    import numpy as np
+    from particlerobotsimulations_amd import make_params
+    f = np.float32
+    max_radius = f(0.1175)
+    cell = float(max_radius * f(2))
+    grid = 2048
+    d = dict(
+        gridSize=(grid, grid), numCells=grid * grid, worldOrigin=(-240.0, -240.0), cellSize=(cell, cell),
+        nCells=n_bots, nDead=0, gravity=float(f(9.81 * float(f(0.566)))), spring=1000.0, damping=10.0,
+        shear=40.0, attraction=float(f(3.0) * f(0.000015884)), boundaryDamping=-1.0, friction=float(f(0.4)),
+        massFactor=1.0, frictionFactor=1.0, radFactor=2.0, attractionFactor=0.0, constraint=0.5,
+        constraint_contraction=10.0, centroid_steps=24000, centroid_int=10.0, centroid_radius=0.05,
+        light_x=-230.0, light_y=0.0, phase_update_interval=12.0, control=0, config=4,
+        min_radius=float(f(0.0775)), max_radius=float(max_radius), rise_period=2.0, freq=float(f(0.5) / f(25)),
+        nobstacles=0, n_cir_obstacles=0, Nx=5, phase_std=0.0, seed=seed, light_shadow=0, testing=0,
+        constrained_contraction=0, display_shadow=0, time_to_dead=0.0, max_time=1e9)
+    return make_params(d)
+
+
+def cpu_baseline(n_bots, budget_s=12.0):
+    """The oracle (our CPU port: the reference has no CPU path) timed on this host's cores on the
+    SAME workload, for a bounded number of steps."""
+    import numpy as np
+    from oracle import orclib
+    P = orclib.default_params(nCells=n_bots, nDead=0, seed=1, phase_std=0.0, max_time=1e9, light_x=-230.0,
+                              light_y=0.0, grid=2048, arena_half=240.0)
+    cores = os.cpu_count() or 1
+    orclib.lib().orc_set_num_threads(cores)
+    sim = orclib.Sim(P, reset=True, hex=True)
+    sim.run(1)  # first step: includes the initial sort
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        sim.run(1)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 200:
+            break
+    sim.close()
+    return {"value": n_bots * steps / el, "unit": "particle-steps/s", "cores": orclib.lib().orc_num_threads(),
+            "kind": "port",
+            "sample": f"{steps} steps of the same {n_bots}-bot arena after 1 warm-up step, OpenMP over bots "
+                      f"({el:.1f} s); reported, not optimised"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2400)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--bots", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        # torch first: its bundled HIP runtime must be the one instance in the process
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import particlerobotsimulations_amd as pb
+
+    if world == 1:
+        pb.legacy.cudaInit(0, None)  # N > 1: torch.cuda.set_device above already chose this rank's GPU
+
+    n = args.bots
+    sp, keep = workload_params(n, seed=1 + rank)
+    sim = pb.Sim(sp, wall_half=240.0, keepalive=keep)
+    pos = hex_lattice(n, np.float32(0.0775) * np.float32(2.0))
+    sim.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
+                  phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
+
+    def barrier():
+        sim.synchronize()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    sim.step(args.warmup)
+    barrier()
+    s0 = sim.stats()
+    t0 = time.perf_counter()
+    done, dev_ms = sim.step_timed(args.steps)
+    barrier()
+    wall = time.perf_counter() - t0
+    s1 = sim.stats()
+    assert done == args.steps, (done, args.steps)
+
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        # the only data exchange of an ensemble: per-arena summaries (time, COMx, COMy), gathered
+        cx, cy = sim.centroid()
+        mine = torch.tensor([sim.time, cx, cy], dtype=torch.float64, device="cuda")
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        summaries = [[float(x) for x in v.tolist()] for v in allv]
+    else:
+        cx, cy = sim.centroid()
+        summaries = [[sim.time, cx, cy]]
+
+    if rank == 0:
+        launches = (s1["fused_launches"] - s0["fused_launches"]) + (s1["plain_launches"] - s0["plain_launches"])
+        value = world * n * args.steps / wall
+        # dominant kernel = k_force (one launch per step); duration from the HIP events recorded on
+        # the simulation's own stream around the timed region
+        avg_launch_s = (dev_ms * 1e-3) / max(launches, 1)
+        achieved = ALG_BYTES_PER_PARTICLE_STEP * n / avg_launch_s / 1e9
+        out = {
+            "metric": "particle-steps/sec at 10^6 bots; achieved HBM GB/s vs peak; 1/2/4/8-GPU ensemble",
+            "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic phototaxis arena: hex lattice of oscillating bots, one light, "
+                                   "2048^2 grid, walls +-240, phase_std 0 (BASELINE configs[2])",
+                       "bots_per_gpu": n, "dt": 0.01, "sort_interval": 180.0,
+                       "parallelism": "single arena" if world == 1 else f"{world} independent arenas, one per GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_force<true> (forces of step n + radius/integration of step n+1)",
+                         "launches": launches, "avg_launch_us": avg_launch_s * 1e6,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * n,
+                         "note": "VALU-bound, not HBM-bound: ~42 neighbour pairs per bot with IEEE div/sqrt "
+                                 "(DESIGN.md 'Roofline')"},
+            "device_ms_timed_region": dev_ms,
+            "summaries_time_comx_comy": summaries,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+/*
+ * particlebot.h -- class Particlebot, headless, on MI355X.
+ *
+ * Keeps the public surface of the reference's class (particlebot.h:14-67): constructor from
+ * SimParams, update, reset, getArray/setArray, the buffer getters, dumpParticlebot, loadFromFile,
+ * getWorldOrigin/getCellSize.  What changed underneath:
+ *   - no OpenGL: the VBO getters return 0 / nullptr unless the legacy engine is selected, in which
+ *     case they return the headless buffer ids / device pointers;
+ *   - the per-step work runs in the resident fused engine (pbSim*, include/particlebot_hip.h) by
+ *     default; PB_ENGINE=legacy (or Engine::Legacy) replays the reference's own call sequence
+ *     through the `extern "C"` device boundary instead, kernel by kernel;
+ *   - absForce_a / absForce_r start at zero (the reference reads them uninitialised at step 0);
+ *   - phase noise uses this build's counter RNG, not cuRAND (parity unpinned).
+ */
+#ifndef PARTICLEBOT_H
+#define PARTICLEBOT_H
+
+#include <cstdio>
+#include <vector>
+
+#include "particlebot_hip.h"
+#include "particlebot_kernel.h"
+
+class Particlebot {
+ public:
+  enum class Engine { Fused, Legacy };
+
+  /* particlebot.h:17 -- engine taken from $PB_ENGINE ("legacy" or "fused", default fused);
+   * wall half-extent 64 as in the reference */
+  Particlebot(SimParams params);
+  Particlebot(SimParams params, Engine engine, float wallHalf);
+  ~Particlebot();
+
+  /* particlebot.h:21.  One timestep (particlebot.cpp:170-300).  Like the reference, exits the
+   * process with status 0 once time > max_time -- unless setExitOnMaxTime(false), after which it
+   * just returns and finished() reports it. */
+  void update(float deltaTime, float sort_interval);
+  /* Extension: up to nsteps timesteps in one call (lets the fused engine keep one kernel per
+   * step); never exits the process; returns the number of steps run. */
+  int advance(float deltaTime, float sort_interval, int nsteps);
+  void reset(); /* particlebot.h:22 */
+
+  /* particlebot.h:24-25.  getArray returns the host mirror after copying n*width floats (the
+   * reference copies nCells*4 floats from 1- and 2-float buffers, particlebot.cpp:830: not
+   * replicated).  PHASE and DEAD are supported too. */
+  float *getArray(ParticlebotArray array);
+  void setArray(ParticlebotArray array, const float *data, int start, int count);
+
+  unsigned int getCurrentReadBuffer() const { return posVbo; }
+  unsigned int getColorBuffer() const { return colorVBO; }
+  unsigned int getRadBuffer() const { return radVbo; }
+  void *getCudaPosVBO() const { return (void *)cudaPosVBO; }
+  void *getCudaColorVBO() const { return (void *)cudaColorVBO; }
+  void *getCudaRadVBO() const { return (void *)cudaRadVBO; }
+
+  /* particlebot.h:54-59 */
+  void dumpParticlebot(uint start, uint count, FILE *fp, float dump_interval, uint testing, float light_x,
+                       float light_y);
+  void loadFromFile(uint start, uint count, FILE *fp, float dump_interval);
+
+  float2 getWorldOrigin() { return params.worldOrigin; }
+  float2 getCellSize() { return params.cellSize; }
+
+  /* ---- extensions ---- */
+  void setExitOnMaxTime(bool on) { exitOnMaxTime = on; }
+  bool finished() const { return time > params.max_time; }
+  float getTime() const { return time; }
+  void setTime(float t);
+  /* true if a dump row is due at the current time (the test at particlebot.cpp:309) */
+  bool dumpDue(float dump_interval) const;
+  /* steps until the next host-side event (dump row, dead-bot draw), for batching; >= 1 */
+  int stepsUntilHostEvent(float deltaTime, float dump_interval, int maxSteps) const;
+  Engine engine() const { return engineKind; }
+  const SimParams &getParams() const { return params; }
+  int *getDeadArray();
+  /* quiet the reference's per-bot "Placing %d th disc" chatter (particlebot.cpp:645) */
+  static void setVerbosePlacement(bool on);
+  pbSim *engineHandle() { return sim; }
+
+ protected:
+  void _initialize();
+  void _finalize();
+  void initGrid(uint2 size, float spacing, float jitter, uint numParticles);
+  void initHexGrid(uint numParticles, float spacing);
+  void placeRandom();
+  void drawDeadBots();
+  void pullState(bool pos, bool vel, bool rad);
+  void legacyUpdate(float deltaTime, float sort_interval);
+
+  /* host mirrors (original bot order) */
+  std::vector<float> hPosV, hVelV, hRadV, hPhaseV, hFreqV;
+  std::vector<int> hDeadV;
+  float *hPos = nullptr, *hVel = nullptr, *hRad = nullptr, *hphase = nullptr;
+  int *hDead = nullptr;
+
+  /* fused engine */
+  pbSim *sim = nullptr;
+
+  /* legacy engine: the reference's device buffers (particlebot.h:93-123) */
+  float *dVel = nullptr, *dAbsForce_a = nullptr, *dAbsForce_r = nullptr, *dphase = nullptr;
+  int *dDead = nullptr;
+  pbRngState *dState = nullptr;
+  float *dSortedPos = nullptr, *dSortedVel = nullptr, *dSortedRad = nullptr;
+  uint *dGridParticleHash = nullptr, *dGridParticleIndex = nullptr, *dCellStart = nullptr, *dCellEnd = nullptr;
+  struct pbGraphicsResource *posRes = nullptr, *radRes = nullptr;
+
+  uint posVbo = 0, colorVBO = 0, radVbo = 0;
+  float *cudaPosVBO = nullptr, *cudaColorVBO = nullptr, *cudaRadVBO = nullptr;
+
+  float time = 0.0f;
+  SimParams params;
+  std::vector<float> obsStore; /* owns copies of the caller's obstacle arrays */
+  uint2 particlebotConfigSize;
+  Engine engineKind = Engine::Fused;
+  float wallHalf = 64.0f;
+  bool exitOnMaxTime = true;
+};
+
+#endif /* PARTICLEBOT_H */

@@ -1,0 +1,172 @@
+/*
+ * particlebot_hip.h -- C-ABI of libparticlebot_hip.so (MI355X / gfx950).
+ *
+ * Two seams:
+ *
+ *  (1) The reference's own `extern "C"` device boundary, particlebot.cuh:15-121 (bodies in
+ *      particlebot_cuda.cu:26-384).  Same names, same argument order and meaning, same
+ *      "void + print + exit(EXIT_FAILURE) on error" convention (include/helper_cuda.h:1000-1029).
+ *      Each declaration cites the reference line it replaces.  One global parameter block, default
+ *      stream, caller owns every buffer: exactly the reference's contract.
+ *
+ *  (2) `pbSim*`: the resident, fused engine (new).  Per-instance parameters (many simulations per
+ *      process), status-returning, state kept cell-sorted in HBM between re-sorts, one fused kernel
+ *      per timestep.  This is what Particlebot::update drives by default and what bench.py times.
+ *
+ * Plain pointers and sizes only; no C++ or framework types cross this boundary.
+ */
+#ifndef PARTICLEBOT_HIP_H
+#define PARTICLEBOT_HIP_H
+
+#include <stddef.h>
+
+#include "particlebot_kernel.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Opaque handle standing in for `struct cudaGraphicsResource` (particlebot.cuh:25-30).  In the
+ * headless build a "GL buffer object" is a plain device buffer created with pbCreateBuffer(). */
+struct pbGraphicsResource;
+
+/* Per-bot RNG state crossing the boundary where the reference passes `curandState*`
+ * (particlebot.cuh:73-78, particlebot.h:98).  Counter-based: (seed, bot, draw). */
+typedef struct pbRngState {
+  unsigned seed;
+  unsigned draw;
+} pbRngState;
+
+/* ------------------------------------------------------------------------------------------ */
+/* (1) reference device boundary                                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+void cudaInit(int argc, char **argv);   /* particlebot.cuh:18  ; particlebot_cuda.cu:29-41  */
+void cudaGLInit(int argc, char **argv); /* main.cpp:97         ; particlebot_cuda.cu:43-47  */
+
+/* particlebot.cuh:20 declares `int size` but particlebot_cuda.cu:49 defines `size_t size`
+ * (latent ABI mismatch in the reference); the definition's size_t is what is exported here. */
+void allocateArray(void **devPtr, size_t size);
+void freeArray(void *devPtr); /* particlebot.cuh:21 */
+void threadSync(void);        /* particlebot.cuh:23 */
+
+/* particlebot.cuh:25-26.  If `res` is non-NULL the device pointer is taken from the mapped buffer
+ * object instead of `device` (particlebot_cuda.cu:97-113). */
+void copyArrayFromDevice(void *host, const void *device, struct pbGraphicsResource **res, int size);
+void copyArrayToDevice(void *device, const void *host, int offset, int size);
+
+/* particlebot.cuh:27-30 (GL interop in the reference; plain device buffers here) */
+void registerGLBufferObject(uint vbo, struct pbGraphicsResource **res);
+void unregisterGLBufferObject(struct pbGraphicsResource *res);
+void *mapGLBufferObject(struct pbGraphicsResource **res);
+void unmapGLBufferObject(struct pbGraphicsResource *res);
+
+/* Headless replacements for the GL calls Particlebot makes on its buffer objects
+ * (glGenBuffers+glBufferData particlebot.cpp:871-880; glBufferSubData :843,:862;
+ * glDeleteBuffers :909-912).  Buffers are zero-filled on creation. */
+uint pbCreateBuffer(size_t size);
+void pbBufferSubData(uint vbo, size_t offset, size_t size, const void *data);
+void pbDeleteBuffer(uint vbo);
+
+void setParameters(SimParams *hostParams); /* particlebot.cuh:33 ; particlebot_cuda.cu:111-123 */
+/* Extension: half-extent of the integrator's wall clamp.  The reference hard-codes 64
+ * (particlebot_kernel_impl.cuh:75-97); that is the default. */
+void pbSetWallHalfExtent(float half);
+
+/* particlebot.cuh:35-40 */
+void integrateSystem(float *pos, float *vel, float *rad, float deltaTime, uint nCells, float time);
+/* particlebot.cuh:42-45 */
+void calcHash(uint *gridParticlebotHash, uint *gridParticlebotIndex, float *pos, int nCells);
+/* particlebot.cuh:47-58 */
+void reorderDataAndFindCellStart(uint *cellStart, uint *cellEnd, float *sortedPos, float *sortedVel,
+                                 float *sortedRad, uint *gridParticlebotHash,
+                                 uint *gridParticlebotIndex, float *oldPos, float *oldVel,
+                                 float *oldRad, uint nCells, uint numCells);
+/* particlebot.cuh:63-71 */
+void updateRad_light_wave(float *pos, float *absForce_a, float *absForce_r, float *rad, float *phase,
+                          float time, float deltaTime, int *dead, int nCells);
+/* particlebot.cuh:73 */
+void curand_setup(pbRngState *state, int N);
+/* particlebot.cuh:75-78 */
+void add_normal_noise(pbRngState *state, float *val, float std, int N);
+/* particlebot.cuh:80-85 */
+void updatePhase(float *pos, float *phase, float spacing, float max_d, float min_d, int nCells);
+/* particlebot.cuh:89-94 (display only: feeds the renderer; exported, does nothing) */
+void updateCol(float *rad, float *col, int nCells, float *pos, float *phase, int *dead);
+/* particlebot.cuh:96-107 */
+void collide(float *newVel, float *absForce_a, float *absForce_r, float *sortedPos, float *sortedVel,
+             float *sortedRad, uint *gridParticlebotIndex, uint *cellStart, uint *cellEnd, uint nCells,
+             uint numCells, float deltaTime);
+/* particlebot.cuh:109-115 (display only: centroid trail; exported, does nothing) */
+void calcCOG(float *pos, float *temppos, float *temppos1, int nCells, float time, int hist_steps,
+             float hist_int);
+/* particlebot.cuh:117-119 */
+void sortParticlebots(uint *dGridParticlebotHash, uint *dGridParticlebotIndex, uint nCells);
+
+/* ------------------------------------------------------------------------------------------ */
+/* (2) resident fused engine                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct pbSim pbSim;
+
+enum {
+  PB_OK = 0,
+  PB_ERR_HIP = 1,      /* a HIP runtime call failed; see pbGetLastErrorString() */
+  PB_ERR_ARG = 2,      /* bad argument (null handle, grid not a power of two >= 8, ...) */
+  PB_ERR_NO_DEVICE = 3 /* no gfx950 device visible */
+};
+
+typedef struct pbSimStats {
+  unsigned long long steps;          /* timesteps executed */
+  unsigned long long fused_launches; /* collide + next radius/integrate in one kernel */
+  unsigned long long plain_launches; /* collide-only kernel */
+  unsigned long long state_launches; /* stand-alone radius+integrate kernel */
+  unsigned long long resorts;
+  unsigned long long phase_updates;
+} pbSimStats;
+
+const char *pbGetLastErrorString(void);
+
+/* Creates a simulation of params->nCells bots on the current device.  The parameter block is
+ * copied (obstacle arrays included, at most PB_MAX_OBSTACLES each).  wallHalf <= 0 selects the
+ * reference's 64.  gridSize must be a power of two >= 8 in each dimension.  State starts zeroed
+ * with time = 0; absForce_a/r are zero (the reference reads them uninitialised at step 0). */
+int pbSimCreate(pbSim **out, const SimParams *params, float wallHalf);
+void pbSimDestroy(pbSim *sim);
+
+/* Host arrays in ORIGINAL bot order; NULL pointers leave that array unchanged.
+ * pos, vel: 2*n floats; rad, phase: n floats; dead: n ints. */
+int pbSimSetState(pbSim *sim, const float *pos, const float *vel, const float *rad, const float *phase,
+                  const int *dead);
+/* Same layout; also absForce_a / absForce_r (n floats each).  NULL pointers are skipped. */
+int pbSimGetState(pbSim *sim, float *pos, float *vel, float *rad, float *phase, int *dead,
+                  float *absForce_a, float *absForce_r);
+int pbSimSetTime(pbSim *sim, float time);
+int pbSimGetTime(pbSim *sim, float *time);
+/* Number of phase-noise draws made so far (the k of the counter RNG); settable for resume. */
+int pbSimGetPhaseDraws(pbSim *sim, unsigned *draws);
+int pbSimSetPhaseDraws(pbSim *sim, unsigned draws);
+
+/* Runs up to nsteps iterations of Particlebot::update's schedule (particlebot.cpp:170-300) minus
+ * the host-side dead-bot draw (:178-194, done by the caller through pbSimSetState): phase update
+ * every phase_update_interval, radius actuation, integration, re-hash + stable sort every
+ * sort_interval, neighbour forces, fp32 `time += dt`.  Stops before a step whose start time
+ * exceeds max_time (the reference calls exit(0) there).  *steps_done receives the count.
+ * Asynchronous with respect to the host except at phase updates (4-byte read-back). */
+int pbSimStep(pbSim *sim, float deltaTime, float sort_interval, int nsteps, int *steps_done);
+/* Same, bracketed by HIP events on the simulation's stream; *elapsed_ms is device time. */
+int pbSimStepTimed(pbSim *sim, float deltaTime, float sort_interval, int nsteps, int *steps_done,
+                   float *elapsed_ms);
+int pbSimSynchronize(pbSim *sim);
+
+/* Centre of mass, reduced on the device in a fixed order (double accumulation). */
+int pbSimCentroid(pbSim *sim, double *cx, double *cy);
+int pbSimGetStats(pbSim *sim, pbSimStats *stats);
+/* 0: stale cell lists re-sorted every sort_interval (reference behaviour, default);
+ * 1: re-sort every step (never the default: it changes trajectories). */
+int pbSimSetResortEveryStep(pbSim *sim, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARTICLEBOT_HIP_H */

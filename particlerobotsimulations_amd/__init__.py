@@ -1,0 +1,217 @@
+"""particlerobotsimulations_amd -- MI355X-native particle-robot update loop.
+
+Python is only the scripting shell over the C-ABI of libparticlebot_hip.so (hand-written HIP for
+gfx950): device memory, the reference's `extern "C"` device boundary (`legacy`) and the resident
+fused engine (`Sim`).  The C++ host side (class Particlebot, .cfg loader, headless runner) lives in
+csrc/ and libparticlebot_host.so.
+
+There is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import SimParams, make_params, pbSimStats  # noqa: F401
+
+__all__ = ["Sim", "DeviceArray", "legacy", "SimParams", "make_params", "library_paths"]
+
+
+def library_paths():
+    return {"hip": _capi.HIP_SO, "host": _capi.HOST_SO}
+
+
+class DeviceArray:
+    """A caller-owned device buffer allocated through allocateArray() (particlebot.cuh:20)."""
+
+    def __init__(self, shape, dtype=np.float32, fill=None):
+        self.shape = tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _capi.lib().allocateArray(C.byref(p), max(self.nbytes, 1))
+        self.ptr = p
+        if fill is not None:
+            self.upload(np.full(self.shape, fill, dtype=self.dtype))
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        d.upload(a)
+        return d
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.nbytes == self.nbytes, (a.nbytes, self.nbytes)
+        if self.nbytes:
+            _capi.lib().copyArrayToDevice(self.ptr, _capi.np_ptr(a), 0, self.nbytes)
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            _capi.lib().copyArrayFromDevice(_capi.np_ptr(out), self.ptr, None, self.nbytes)
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            _capi.lib().freeArray(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _Legacy:
+    """The reference's `extern "C"` boundary (particlebot.cuh:15-121), one call per entry point.
+    Arguments are DeviceArray objects; semantics are the reference's."""
+
+    def __getattr__(self, name):
+        return getattr(_capi.lib(), name)
+
+    def set_parameters(self, params, wall_half=64.0):
+        L = _capi.lib()
+        L.pbSetWallHalfExtent(float(wall_half))
+        L.setParameters(C.byref(params))
+
+    def integrate(self, pos, vel, rad, dt, n, time=0.0):
+        _capi.lib().integrateSystem(pos.ptr, vel.ptr, rad.ptr, dt, n, time)
+
+    def calc_hash(self, hash_, index, pos, n):
+        _capi.lib().calcHash(hash_.ptr, index.ptr, pos.ptr, n)
+
+    def sort(self, hash_, index, n):
+        _capi.lib().sortParticlebots(hash_.ptr, index.ptr, n)
+
+    def reorder(self, cell_start, cell_end, spos, svel, srad, hash_, index, pos, vel, rad, n, num_cells):
+        _capi.lib().reorderDataAndFindCellStart(cell_start.ptr, cell_end.ptr, spos.ptr, svel.ptr,
+                                               srad.ptr, hash_.ptr, index.ptr, pos.ptr, vel.ptr,
+                                               rad.ptr, n, num_cells)
+
+    def update_rad(self, pos, abs_a, abs_r, rad, phase, time, dt, dead, n):
+        _capi.lib().updateRad_light_wave(pos.ptr, abs_a.ptr, abs_r.ptr, rad.ptr, phase.ptr, time, dt,
+                                        dead.ptr, n)
+
+    def update_phase(self, pos, phase, spacing, max_d, min_d, n):
+        _capi.lib().updatePhase(pos.ptr, phase.ptr, spacing, max_d, min_d, n)
+
+    def rng_setup(self, state, n):
+        _capi.lib().curand_setup(state.ptr, n)
+
+    def add_noise(self, state, val, std, n):
+        _capi.lib().add_normal_noise(state.ptr, val.ptr, std, n)
+
+    def collide(self, new_vel, abs_a, abs_r, spos, svel, srad, index, cell_start, cell_end, n, num_cells, dt):
+        _capi.lib().collide(new_vel.ptr, abs_a.ptr, abs_r.ptr, spos.ptr, svel.ptr, srad.ptr, index.ptr,
+                           cell_start.ptr, cell_end.ptr, n, num_cells, dt)
+
+    def sync(self):
+        _capi.lib().threadSync()
+
+
+legacy = _Legacy()
+
+
+class Sim:
+    """One resident simulation on the current GPU (pbSim* in include/particlebot_hip.h)."""
+
+    def __init__(self, params, wall_half=0.0, keepalive=None):
+        self._keep = keepalive
+        self.params = params
+        self.n = int(params.nCells)
+        h = C.c_void_p()
+        _capi.check(_capi.lib().pbSimCreate(C.byref(h), C.byref(params), float(wall_half)), "pbSimCreate")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _capi.lib().pbSimDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _in(a, dtype, count):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=dtype).reshape(-1)
+        assert a.size == count, (a.size, count)
+        return a
+
+    def set_state(self, pos=None, vel=None, rad=None, phase=None, dead=None):
+        n = self.n
+        pos = self._in(pos, np.float32, 2 * n)
+        vel = self._in(vel, np.float32, 2 * n)
+        rad = self._in(rad, np.float32, n)
+        phase = self._in(phase, np.float32, n)
+        dead = self._in(dead, np.int32, n)
+        _capi.check(_capi.lib().pbSimSetState(self._h, _capi.np_ptr(pos), _capi.np_ptr(vel), _capi.np_ptr(rad),
+                                              _capi.np_ptr(phase), _capi.np_ptr(dead)), "pbSimSetState")
+
+    def get_state(self):
+        n = self.n
+        out = {
+            "pos": np.empty((n, 2), np.float32), "vel": np.empty((n, 2), np.float32),
+            "rad": np.empty(n, np.float32), "phase": np.empty(n, np.float32),
+            "dead": np.empty(n, np.int32), "absForce_a": np.empty(n, np.float32),
+            "absForce_r": np.empty(n, np.float32),
+        }
+        _capi.check(_capi.lib().pbSimGetState(self._h, *[_capi.np_ptr(out[k]) for k in
+                                                         ("pos", "vel", "rad", "phase", "dead",
+                                                          "absForce_a", "absForce_r")]), "pbSimGetState")
+        return out
+
+    @property
+    def time(self):
+        t = C.c_float()
+        _capi.check(_capi.lib().pbSimGetTime(self._h, C.byref(t)))
+        return t.value
+
+    @time.setter
+    def time(self, t):
+        _capi.check(_capi.lib().pbSimSetTime(self._h, float(t)))
+
+    @property
+    def phase_draws(self):
+        d = C.c_uint()
+        _capi.check(_capi.lib().pbSimGetPhaseDraws(self._h, C.byref(d)))
+        return d.value
+
+    @phase_draws.setter
+    def phase_draws(self, d):
+        _capi.check(_capi.lib().pbSimSetPhaseDraws(self._h, int(d)))
+
+    def step(self, nsteps, dt=0.01, sort_interval=180.0):
+        done = C.c_int()
+        _capi.check(_capi.lib().pbSimStep(self._h, dt, sort_interval, int(nsteps), C.byref(done)), "pbSimStep")
+        return done.value
+
+    def step_timed(self, nsteps, dt=0.01, sort_interval=180.0):
+        done = C.c_int()
+        ms = C.c_float()
+        _capi.check(_capi.lib().pbSimStepTimed(self._h, dt, sort_interval, int(nsteps), C.byref(done),
+                                               C.byref(ms)), "pbSimStepTimed")
+        return done.value, ms.value
+
+    def synchronize(self):
+        _capi.check(_capi.lib().pbSimSynchronize(self._h))
+
+    def centroid(self):
+        cx, cy = C.c_double(), C.c_double()
+        _capi.check(_capi.lib().pbSimCentroid(self._h, C.byref(cx), C.byref(cy)), "pbSimCentroid")
+        return cx.value, cy.value
+
+    def stats(self):
+        s = pbSimStats()
+        _capi.check(_capi.lib().pbSimGetStats(self._h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in pbSimStats._fields_}
+
+    def set_resort_every_step(self, on):
+        _capi.check(_capi.lib().pbSimSetResortEveryStep(self._h, 1 if on else 0))

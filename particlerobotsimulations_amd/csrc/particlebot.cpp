@@ -1,0 +1,620 @@
+// particlebot.cpp -- host side of class Particlebot (headless, MI355X).
+//
+// Mirrors the behaviour of the reference's particlebot.cpp (cited per method) without its OpenGL
+// storage: host mirrors + either the resident fused engine (pbSim*) or, for Engine::Legacy, the
+// reference's own kernel-by-kernel call sequence through the `extern "C"` device boundary.
+//
+// Host arithmetic that decides results (placement accept/reject, the min-distance square root,
+// the CSV distance column, the dead-bot draw) uses libc rand()/powf/cosf/sinf exactly where the
+// reference does; compile with -ffp-contract=off.
+#include "particlebot.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace {
+
+bool g_verbosePlacement = false;
+constexpr float kPi = 3.141592654f;  // particlebot.cpp:21-23
+
+inline float frand() { return rand() / (float)RAND_MAX; }  // particlebot.cpp:27-30
+// particlebot.cpp:32-34: the host-side length() is powf-based, unlike the device one
+inline float hostLength(float x, float y) { return powf(powf(x, 2.0f) + powf(y, 2.0f), 0.5f); }
+
+inline bool everyGate(float t, float interval, float dt) { return t - interval * floorf(t / interval) < dt; }
+
+void die(const char *what) {
+  fprintf(stderr, "Particlebot: %s: %s\n", what, pbGetLastErrorString());
+  exit(EXIT_FAILURE);
+}
+
+// Occupancy lists of the placement grid.  The reference keeps vector<vector<vector<int>>> indexed
+// [x][y] (particlebot.cpp:614-623); the scans only ever ask "is any listed bot closer than 2 r_min",
+// so a chained list per cell is equivalent.  Cells outside the grid (which the reference indexes
+// out of bounds, :689-691) are treated as empty.
+struct PlacementGrid {
+  uint gx, gy;
+  float ox, oy, cx, cy;
+  std::vector<int> head, next;
+  PlacementGrid(const SimParams &p, uint n)
+      : gx(p.gridSize.x), gy(p.gridSize.y), ox(p.worldOrigin.x), oy(p.worldOrigin.y), cx(p.cellSize.x),
+        cy(p.cellSize.y), head((size_t)p.gridSize.x * p.gridSize.y, -1), next(n, -1) {}
+  int col(float x) const { return ((int)floorf((x - ox) / cx)) & (int)(gx - 1); }
+  int row(float y) const { return ((int)floorf((y - oy) / cy)) & (int)(gy - 1); }
+  void add(int bot, float x, float y) {
+    const size_t c = (size_t)col(x) * gy + (size_t)row(y);
+    next[bot] = head[c];
+    head[c] = bot;
+  }
+  // any listed bot within `limit` of (x,y) in the 3x3 cells around it?
+  bool crowded(float x, float y, const float *pos, double limit) const {
+    const int xc = col(x), yc = row(y);
+    for (int xg = xc - 1; xg <= xc + 1; xg++)
+      for (int yg = yc - 1; yg <= yc + 1; yg++) {
+        if (xg < 0 || yg < 0 || xg >= (int)gx || yg >= (int)gy) continue;
+        for (int b = head[(size_t)xg * gy + yg]; b >= 0; b = next[b])
+          if (hostLength(x - pos[2 * b], y - pos[2 * b + 1]) < limit) return true;
+      }
+    return false;
+  }
+};
+
+}  // namespace
+
+void Particlebot::setVerbosePlacement(bool on) { g_verbosePlacement = on; }
+
+Particlebot::Particlebot(SimParams simparams) : Particlebot(simparams, Engine::Fused, 64.0f) {}
+
+Particlebot::Particlebot(SimParams simparams, Engine engine, float wall) : time(0) {
+  params = simparams;
+  engineKind = engine;
+  if (const char *e = getenv("PB_ENGINE")) {
+    if (!strcmp(e, "legacy")) engineKind = Engine::Legacy;
+    if (!strcmp(e, "fused")) engineKind = Engine::Fused;
+  }
+  wallHalf = wall > 0.0f ? wall : 64.0f;
+  particlebotConfigSize.x = particlebotConfigSize.y = 0;
+  // The reference shallow-copies the obstacle pointers (particlebot.cpp:43); own them instead.
+  const int nr = params.nobstacles > 0 ? params.nobstacles : 0, nc = params.n_cir_obstacles > 0 ? params.n_cir_obstacles : 0;
+  obsStore.assign((size_t)4 * nr + (size_t)3 * nc + 1, 0.0f);
+  float *w = obsStore.data();
+  auto own = [&](float *&field, int cnt) {
+    for (int i = 0; i < cnt; i++) w[i] = field ? field[i] : 0.0f;
+    field = w;
+    w += cnt;
+  };
+  own(params.x1obs, nr);
+  own(params.x2obs, nr);
+  own(params.y1obs, nr);
+  own(params.y2obs, nr);
+  own(params.x_cir_obs, nc);
+  own(params.y_cir_obs, nc);
+  own(params.r_cir_obs, nc);
+  _initialize();
+}
+
+Particlebot::~Particlebot() { _finalize(); }
+
+void Particlebot::_initialize() {
+  // particlebot.cpp:77-166 minus GL.  Host mirrors are zeroed; device state starts zeroed too.
+  const size_t n = params.nCells;
+  hPosV.assign(2 * n, 0.0f);
+  hVelV.assign(2 * n, 0.0f);
+  hRadV.assign(n, 0.0f);
+  hPhaseV.assign(n, 0.0f);
+  hFreqV.assign(n, 0.0f);
+  hDeadV.assign(n, 0);
+  hPos = hPosV.data();
+  hVel = hVelV.data();
+  hRad = hRadV.data();
+  hphase = hPhaseV.data();
+  hDead = hDeadV.data();
+
+  if (engineKind == Engine::Fused) {
+    if (pbSimCreate(&sim, &params, wallHalf) != PB_OK) die("pbSimCreate");
+    return;
+  }
+  // Engine::Legacy: the reference's buffers (particlebot.cpp:101-165)
+  cudaInit(0, nullptr);
+  const size_t memSize = sizeof(float) * 2 * n;
+  posVbo = pbCreateBuffer(memSize);
+  registerGLBufferObject(posVbo, &posRes);
+  radVbo = pbCreateBuffer(sizeof(float) * n);
+  registerGLBufferObject(radVbo, &radRes);
+  cudaPosVBO = (float *)mapGLBufferObject(&posRes);
+  cudaRadVBO = (float *)mapGLBufferObject(&radRes);
+  allocateArray((void **)&dVel, memSize);
+  allocateArray((void **)&dSortedPos, memSize);
+  allocateArray((void **)&dSortedVel, memSize);
+  allocateArray((void **)&dSortedRad, sizeof(float) * n);
+  allocateArray((void **)&dphase, sizeof(float) * n);
+  allocateArray((void **)&dAbsForce_a, sizeof(float) * n);
+  allocateArray((void **)&dAbsForce_r, sizeof(float) * n);
+  allocateArray((void **)&dGridParticleHash, n * sizeof(uint));
+  allocateArray((void **)&dGridParticleIndex, n * sizeof(uint));
+  allocateArray((void **)&dCellStart, params.numCells * sizeof(uint));
+  allocateArray((void **)&dCellEnd, params.numCells * sizeof(uint));
+  allocateArray((void **)&dDead, sizeof(int) * n);
+  allocateArray((void **)&dState, sizeof(pbRngState) * n);
+  // zero what the reference leaves uninitialised
+  std::vector<float> zeros(2 * n, 0.0f);
+  copyArrayToDevice(dVel, zeros.data(), 0, (int)memSize);
+  copyArrayToDevice(dAbsForce_a, zeros.data(), 0, (int)(sizeof(float) * n));
+  copyArrayToDevice(dAbsForce_r, zeros.data(), 0, (int)(sizeof(float) * n));
+  copyArrayToDevice(dphase, zeros.data(), 0, (int)(sizeof(float) * n));
+  copyArrayToDevice(dDead, hDead, 0, (int)(sizeof(int) * n));
+  copyArrayToDevice(dGridParticleHash, zeros.data(), 0, (int)(sizeof(uint) * n));
+  copyArrayToDevice(dGridParticleIndex, zeros.data(), 0, (int)(sizeof(uint) * n));
+  pbSetWallHalfExtent(wallHalf);
+  setParameters(&params);
+  curand_setup(dState, (int)n);
+}
+
+void Particlebot::_finalize() {
+  if (sim) {
+    pbSimDestroy(sim);
+    sim = nullptr;
+  }
+  if (engineKind == Engine::Legacy && dVel) {
+    freeArray(dVel);
+    freeArray(dSortedPos);
+    freeArray(dSortedVel);
+    freeArray(dSortedRad);
+    freeArray(dphase);
+    freeArray(dAbsForce_a);
+    freeArray(dAbsForce_r);
+    freeArray(dGridParticleHash);
+    freeArray(dGridParticleIndex);
+    freeArray(dCellStart);
+    freeArray(dCellEnd);
+    freeArray(dDead);
+    freeArray(dState);
+    unregisterGLBufferObject(posRes);
+    unregisterGLBufferObject(radRes);
+    pbDeleteBuffer(posVbo);
+    pbDeleteBuffer(radVbo);
+    dVel = nullptr;
+  }
+}
+
+// ---- stepping ---------------------------------------------------------------------------------
+
+void Particlebot::drawDeadBots() {
+  // particlebot.cpp:178-194: nDead distinct bots, rand() % remaining + erase
+  std::vector<int> inds;
+  inds.reserve(params.nCells);
+  for (uint i = 0; i < params.nCells; i++) inds.push_back((int)i);
+  int count = 0;
+  while (count < params.nDead) {
+    const int i = rand() % inds.size();
+    hDead[inds[i]] = 1;
+    inds.erase(inds.begin() + i);
+    count++;
+  }
+  if (engineKind == Engine::Fused) {
+    if (pbSimSetState(sim, nullptr, nullptr, nullptr, nullptr, hDead) != PB_OK) die("pbSimSetState(dead)");
+  } else {
+    copyArrayToDevice(dDead, hDead, 0, (int)(params.nCells * sizeof(int)));
+  }
+}
+
+void Particlebot::legacyUpdate(float deltaTime, float sort_interval) {
+  // particlebot.cpp:196-299, call for call (minus calcCOG/updateCol, which only feed the renderer)
+  float *dPos = (float *)mapGLBufferObject(&posRes);
+  float *dRad = (float *)mapGLBufferObject(&radRes);
+  unmapGLBufferObject(posRes);
+  unmapGLBufferObject(radRes);
+  const uint n = params.nCells;
+  if (params.control == LIGHT_WAVE) {
+    if (everyGate(time, params.phase_update_interval, deltaTime)) {
+      copyArrayFromDevice(hPos, dPos, 0, (int)(sizeof(float) * 2 * n));
+      float min_d = 0, max_d = 0, dist = 0;
+      for (uint i = 0; i < n; i++) {
+        dist = powf(powf(params.light_x - hPos[i * 2], 2) + powf(params.light_y - hPos[i * 2 + 1], 2), 0.5f);
+        if (i == 0) {
+          max_d = dist;
+          min_d = dist;
+        } else {
+          min_d = (min_d < dist ? min_d : dist);
+          max_d = (max_d > dist ? max_d : dist);
+        }
+      }
+      const float spacing = 2.0f * params.min_radius;
+      updatePhase(dPos, dphase, spacing, max_d, min_d, (int)n);
+      if (params.phase_std) add_normal_noise(dState, dphase, params.phase_std, (int)n);
+    }
+    if (time >= 0) updateRad_light_wave(dPos, dAbsForce_a, dAbsForce_r, dRad, dphase, time, deltaTime, dDead, (int)n);
+  }
+  integrateSystem(dPos, dVel, dRad, deltaTime, n, time);
+  if (everyGate(time, sort_interval, deltaTime)) {
+    calcHash(dGridParticleHash, dGridParticleIndex, dPos, (int)n);
+    sortParticlebots(dGridParticleHash, dGridParticleIndex, n);
+  }
+  reorderDataAndFindCellStart(dCellStart, dCellEnd, dSortedPos, dSortedVel, dSortedRad, dGridParticleHash,
+                              dGridParticleIndex, dPos, dVel, dRad, n, params.numCells);
+  collide(dVel, dAbsForce_a, dAbsForce_r, dSortedPos, dSortedVel, dSortedRad, dGridParticleIndex, dCellStart,
+          dCellEnd, n, params.numCells, deltaTime);
+  time = time + deltaTime;
+}
+
+void Particlebot::update(float deltaTime, float sort_interval) {
+  if (time > params.max_time) {
+    if (exitOnMaxTime) exit(0);  // particlebot.cpp:174-176
+    return;
+  }
+  advance(deltaTime, sort_interval, 1);
+}
+
+int Particlebot::advance(float deltaTime, float sort_interval, int nsteps) {
+  int total = 0;
+  const bool draws = params.nDead > 0;
+  auto deadGate = [&](float t) { return t >= params.time_to_dead && t < params.time_to_dead + deltaTime; };
+  while (total < nsteps) {
+    if (time > params.max_time) break;
+    if (draws && deadGate(time)) drawDeadBots();
+    int run = nsteps - total;
+    if (draws) {
+      // stop the batch in front of the next step whose start time opens the dead-bot window
+      run = 1;
+      float t = time + deltaTime;
+      while (total + run < nsteps && !deadGate(t)) {
+        t = t + deltaTime;
+        run++;
+      }
+    }
+    if (engineKind == Engine::Fused) {
+      int done = 0;
+      if (pbSimStep(sim, deltaTime, sort_interval, run, &done) != PB_OK) die("pbSimStep");
+      if (pbSimGetTime(sim, &time) != PB_OK) die("pbSimGetTime");
+      total += done;
+      if (done < run) break;
+    } else {
+      int done = 0;
+      for (; done < run && !(time > params.max_time); done++) legacyUpdate(deltaTime, sort_interval);
+      total += done;
+      if (done < run) break;
+    }
+  }
+  return total;
+}
+
+void Particlebot::setTime(float t) {
+  time = t;
+  if (sim && pbSimSetTime(sim, t) != PB_OK) die("pbSimSetTime");
+}
+
+bool Particlebot::dumpDue(float dump_interval) const {
+  return !(time - dump_interval * floorf(time / dump_interval) > 0.01f);  // particlebot.cpp:309
+}
+
+int Particlebot::stepsUntilHostEvent(float deltaTime, float dump_interval, int maxSteps) const {
+  // replay the fp32 clock to find the next step whose start time makes a dump row due
+  float t = time + deltaTime;
+  int k = 1;
+  while (k < maxSteps && (t - dump_interval * floorf(t / dump_interval) > 0.01f) && !(t > params.max_time)) {
+    t = t + deltaTime;
+    k++;
+  }
+  return k;
+}
+
+// ---- state access -----------------------------------------------------------------------------
+
+void Particlebot::pullState(bool pos, bool vel, bool rad) {
+  const uint n = params.nCells;
+  if (engineKind == Engine::Fused) {
+    if (pbSimGetState(sim, pos ? hPos : nullptr, vel ? hVel : nullptr, rad ? hRad : nullptr, nullptr, nullptr,
+                      nullptr, nullptr) != PB_OK)
+      die("pbSimGetState");
+  } else {
+    if (pos) copyArrayFromDevice(hPos, 0, &posRes, (int)(sizeof(float) * 2 * n));
+    if (vel) copyArrayFromDevice(hVel, dVel, 0, (int)(sizeof(float) * 2 * n));
+    if (rad) copyArrayFromDevice(hRad, 0, &radRes, (int)(sizeof(float) * n));
+  }
+}
+
+float *Particlebot::getArray(ParticlebotArray array) {
+  const uint n = params.nCells;
+  switch (array) {
+    default:
+    case POSITION: pullState(true, false, false); return hPos;
+    case VELOCITY: pullState(false, true, false); return hVel;
+    case RADII: pullState(false, false, true); return hRad;
+    case PHASE:
+      if (engineKind == Engine::Fused) {
+        if (pbSimGetState(sim, nullptr, nullptr, nullptr, hphase, nullptr, nullptr, nullptr) != PB_OK)
+          die("pbSimGetState");
+      } else {
+        copyArrayFromDevice(hphase, dphase, 0, (int)(sizeof(float) * n));
+      }
+      return hphase;
+  }
+}
+
+int *Particlebot::getDeadArray() {
+  if (engineKind == Engine::Fused) {
+    if (pbSimGetState(sim, nullptr, nullptr, nullptr, nullptr, hDead, nullptr, nullptr) != PB_OK) die("pbSimGetState");
+  } else {
+    copyArrayFromDevice(hDead, dDead, 0, (int)(sizeof(int) * params.nCells));
+  }
+  return hDead;
+}
+
+void Particlebot::setArray(ParticlebotArray array, const float *data, int start, int count) {
+  // particlebot.cpp:834-867.  The reference's POSITION/RADII buffers carry centroid_steps+1 extra
+  // display entries; only the nCells bots exist here, so longer ranges are clipped.
+  const int n = (int)params.nCells;
+  if (start < 0 || start >= n || count <= 0) return;
+  if (start + count > n) count = n - start;
+  const bool fused = engineKind == Engine::Fused;
+  switch (array) {
+    default:
+    case POSITION:
+      if (data != hPos + 2 * start) memcpy(hPos + 2 * start, data, sizeof(float) * 2 * count);
+      if (fused) {
+        if (pbSimSetState(sim, hPos, nullptr, nullptr, nullptr, nullptr) != PB_OK) die("pbSimSetState");
+      } else {
+        pbBufferSubData(posVbo, sizeof(float) * 2 * start, sizeof(float) * 2 * count, data);
+      }
+      break;
+    case VELOCITY:
+      if (data != hVel + 2 * start) memcpy(hVel + 2 * start, data, sizeof(float) * 2 * count);
+      if (fused) {
+        if (pbSimSetState(sim, nullptr, hVel, nullptr, nullptr, nullptr) != PB_OK) die("pbSimSetState");
+      } else {
+        copyArrayToDevice(dVel, data, (int)(start * 2 * sizeof(float)), (int)(count * 2 * sizeof(float)));
+      }
+      break;
+    case PHASE:
+      if (data != hphase + start) memcpy(hphase + start, data, sizeof(float) * count);
+      if (fused) {
+        if (pbSimSetState(sim, nullptr, nullptr, nullptr, hphase, nullptr) != PB_OK) die("pbSimSetState");
+      } else {
+        copyArrayToDevice(dphase, data, (int)(start * sizeof(float)), (int)(count * sizeof(float)));
+      }
+      break;
+    case FREQUENCY:  // stored, never read by any kernel (as in the reference)
+      memcpy(hFreqV.data() + start, data, sizeof(float) * count);
+      break;
+    case RADII:
+      if (data != hRad + start) memcpy(hRad + start, data, sizeof(float) * count);
+      if (fused) {
+        if (pbSimSetState(sim, nullptr, nullptr, hRad, nullptr, nullptr) != PB_OK) die("pbSimSetState");
+      } else {
+        pbBufferSubData(radVbo, sizeof(float) * start, sizeof(float) * count, data);
+      }
+      break;
+  }
+}
+
+// ---- CSV dump / reload ------------------------------------------------------------------------
+
+void Particlebot::dumpParticlebot(uint start, uint count, FILE *fp, float dump_interval, uint testing,
+                                  float light_x, float light_y) {
+  // particlebot.cpp:303-367, same text byte for byte
+  float sumX = 0.0f;
+  float sumY = 0.0f;
+  if (time - dump_interval * floorf(time / dump_interval) > 0.01f) return;
+  pullState(true, true, true);
+  if (time == 0) {
+    fprintf(fp, "Seed, %u\n", params.seed);
+    fprintf(fp, "Time,");
+    if (testing) {
+      for (uint i = start; i < start + count; i++) fprintf(fp, "Particlebot_%d_xpos, Particlebot_%d_ypos,", i, i);
+      for (uint i = start; i < start + count; i++) fprintf(fp, "Particlebot_%d_xvel, Particlebot_%d_yvel,", i, i);
+      for (uint i = start; i < start + count; i++) fprintf(fp, "Particlebot_%d_rad,", i);
+    }
+    fprintf(fp, "Centroid X, Centroid Y, Distance");
+    fprintf(fp, "\n");
+  }
+  fprintf(fp, "%f,", time);
+  if (testing) {
+    for (uint i = start; i < start + count; i++) fprintf(fp, "%f, %f,", hPos[i * 2 + 0], hPos[i * 2 + 1]);
+    for (uint i = start; i < start + count; i++) fprintf(fp, "%f, %f,", hVel[i * 2 + 0], hVel[i * 2 + 1]);
+    for (uint i = start; i < start + count; i++) fprintf(fp, "%f,", hRad[i]);
+  }
+  for (uint i = start; i < start + count; i++) {
+    sumX += hPos[i * 2 + 0];
+    sumY += hPos[i * 2 + 1];
+  }
+  fprintf(fp, "%f, %f, %f,", sumX / (float)count, sumY / (float)count,
+          powf(powf(sumX / (float)count - light_x, 2.0) + powf(sumY / (float)count - light_y, 2.0), 0.5));
+  fprintf(fp, "\n");
+  printf("%f %f %f \n", time, sumX / (float)count, sumY / (float)count);
+}
+
+void Particlebot::loadFromFile(uint start, uint count, FILE *fp, float) {
+  // particlebot.cpp:369-411: last complete row of a testing=1 CSV -> time, pos, vel, rad
+  fseek(fp, 0, SEEK_SET);
+  int c = fgetc(fp);
+  long bytes = 1, prevLine = 0, lastLine = 0;
+  while (c != EOF) {
+    if (c == '\n') {
+      prevLine = lastLine;
+      lastLine = bytes;
+    }
+    c = fgetc(fp);
+    bytes += 1;
+  }
+  fseek(fp, prevLine - bytes, SEEK_END);
+  float t = 0;
+  if (fscanf(fp, "%f,", &t) != 1) return;
+  for (uint i = start; i < start + count; i++)
+    if (fscanf(fp, "%f, %f,", &hPos[i * 2 + 0], &hPos[i * 2 + 1]) != 2) return;
+  for (uint i = start; i < start + count; i++)
+    if (fscanf(fp, "%f, %f,", &hVel[i * 2 + 0], &hVel[i * 2 + 1]) != 2) return;
+  for (uint i = start; i < start + count; i++)
+    if (fscanf(fp, "%f,", &hRad[i]) != 1) return;
+  setTime(t);
+  setArray(RADII, hRad, 0, params.nCells);
+  setArray(POSITION, hPos, 0, params.nCells);
+  setArray(VELOCITY, hVel, 0, params.nCells);
+  printf("Time = %f\n", time);
+}
+
+// ---- initial placement --------------------------------------------------------------------------
+
+void Particlebot::initGrid(uint2 size, float spacing, float jitter, uint nCells) {
+  // particlebot.cpp:413-436 (y is forced to 0 there: a line of bots)
+  const float xs = size.x * spacing / 2.0f;
+  for (uint y = 0; y < size.y; y++)
+    for (uint x = 0; x < size.x; x++) {
+      const uint i = (y * size.x) + x;
+      if (i < nCells) {
+        hPos[i * 2] = (spacing * x) + params.min_radius - xs + (frand() * 2.0f - 1.0f) * jitter;
+        hPos[i * 2 + 1] = 0;
+        hVel[i * 2] = 0.0f;
+        hVel[i * 2 + 1] = 0.0f;
+      }
+    }
+}
+
+void Particlebot::initHexGrid(uint nCells, float spacing) {
+  // particlebot.cpp:438-481: concentric hexagonal rings around the origin
+  const float h = powf(3, 0.5f) * 0.5f;
+  const float ux[7] = {1.0f, 0.5f, -0.5f, -1.0f, -0.5f, 0.5f, 1.0f};
+  const float uy[7] = {0.0f, h, h, 0.0f, -h, -h, 0.0f};
+  if (nCells == 0) return;
+  uint i = 0;
+  hPos[0] = 0.0f;
+  hPos[1] = 0.0f;
+  hVel[0] = hVel[1] = 0.0f;
+  i++;
+  int ring = 1;
+  while (i < nCells) {
+    for (int k = 0; k < 6 && i < nCells; k++)
+      for (int j = 0; j < ring && i < nCells; j++) {
+        hPos[i * 2] = ux[k] * (ring - j) * spacing + ux[k + 1] * spacing * j;
+        hPos[i * 2 + 1] = uy[k] * (ring - j) * spacing + uy[k + 1] * spacing * j;
+        hVel[i * 2] = 0.0f;
+        hVel[i * 2 + 1] = 0.0f;
+        i++;
+      }
+    ring++;
+  }
+  particlebotConfigSize.x = particlebotConfigSize.y = ring * 2;
+}
+
+void Particlebot::placeRandom() {
+  // particlebot.cpp:612-748.  Seed bot at (5,0); bot 2 perpendicular to the first pair; every
+  // other bot: random anchor, random direction, reject if crowded, then pivot in 10-degree steps
+  // until the next position would touch something.  After 200 rejections the ring widens.
+  const uint n = params.nCells;
+  if (n == 0) return;
+  PlacementGrid grid(params, n);
+  particlebotConfigSize.x = (int)ceilf(powf((float)n, 1.0f / 2.0f));
+  const double touch = 2 * 1.0 * params.min_radius;
+  const float pivot = 2 * kPi / 360.0 * 10.0;
+  const uint maxRejections = 200;
+  uint rejections = 0;
+  float lowestX = 9999999.0;
+  hPos[0] = 5.0;
+  hPos[1] = 0.0;
+  grid.add(0, 0.0f, 0.0f);  // sic: the reference bins bot 0 at the origin's cell (:635-637)
+  float x = 0, y = 0;
+  for (uint i = 1; i < n; i++) {
+    if (g_verbosePlacement) printf("Placing %d th disc\n", i);
+    if (i == 2) {
+      const int side = rand() % 2;
+      float dx = hPos[2] - hPos[0], dy = hPos[3] - hPos[1];
+      const float l = hostLength(dx, dy);
+      dy = dy / l;
+      dx = dx / l;
+      const float px = side ? dy : -dy, py = side ? -dx : dx;
+      x = (hPos[2] + hPos[0]) / 2.0f + px * params.min_radius;
+      y = (hPos[3] + hPos[1]) / 2.0f + py * params.min_radius;
+      if (x < lowestX) lowestX = x;
+      hPos[2 * i] = x;
+      hPos[2 * i + 1] = y;
+      grid.add((int)i, x, y);
+      continue;
+    }
+    float r = params.min_radius;
+    for (;;) {
+      const uint anchor = (uint)rand() % i;
+      if (rejections == maxRejections) {
+        rejections = 0;
+        r += params.min_radius;
+      }
+      float theta = 2 * frand() * kPi;
+      x = hPos[2 * anchor] + 2 * r * cosf(theta);
+      y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
+      if (grid.crowded(x, y, hPos, touch)) {
+        rejections++;
+        continue;
+      }
+      const float theta0 = theta;
+      while (theta - theta0 < 2 * kPi) {
+        theta += pivot;
+        x = hPos[2 * anchor] + 2 * r * cosf(theta);
+        y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
+        if (grid.crowded(x, y, hPos, touch)) {
+          theta -= pivot;
+          break;
+        }
+      }
+      x = hPos[2 * anchor] + 2 * r * cosf(theta);
+      y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
+      break;
+    }
+    if (x < lowestX) lowestX = x;
+    if (params.nDead == -1 && i == n - 1) {  // the payload sits left of the blob (:731-735)
+      x = lowestX - 1 * params.min_radius * params.radFactor - 2 * params.min_radius;
+      y = 0;
+    }
+    hPos[2 * i] = x;
+    hPos[2 * i + 1] = y;
+    grid.add((int)i, x, y);
+  }
+}
+
+void Particlebot::reset() {
+  // particlebot.cpp:485-801.  CONFIG_RANDOM, CONFIG_HEX, CONFIG_GRID and CONFIG_LINE are built;
+  // the three hard-coded 10-bot presets (:492-611) are not (they assert nCells == 10 and are
+  // unreachable from a .cfg: the config key never takes effect, main.cpp:794-809).
+  time = 0;
+  if (sim) pbSimSetTime(sim, 0.0f);
+  const uint n = params.nCells;
+  std::fill(hVelV.begin(), hVelV.end(), 0.0f);
+  switch (params.config) {
+    case CONFIG_HEX:
+      particlebotConfigSize.x = (int)ceilf(powf((float)n, 1.0f / 2.0f));
+      initHexGrid(n, params.min_radius * 2.0f);
+      break;
+    case CONFIG_GRID: {
+      const float jitter = params.max_radius * 0.01f;
+      const uint s = (int)ceilf(powf((float)n, 1.0f / 2.0f));
+      particlebotConfigSize.x = particlebotConfigSize.y = s;
+      initGrid(particlebotConfigSize, params.min_radius * 2.0f, jitter, n);
+    } break;
+    case CONFIG_LINE:
+      particlebotConfigSize.x = n;
+      particlebotConfigSize.y = 1;
+      initGrid(particlebotConfigSize, params.min_radius * 2.0f, params.max_radius * 0.00f, n);
+      break;
+    case CONFIG_RANDOM:
+    default:
+      placeRandom();
+      break;
+  }
+  if (!params.Nx) params.Nx = particlebotConfigSize.x;
+  for (uint i = 0; i < n; i++) {
+    hRad[i] = params.min_radius;
+    if (params.nDead == -1 && i == n - 1) {
+      hRad[i] = params.min_radius * params.radFactor;
+      hDead[i] = 1;
+    }
+    hphase[i] = 0;
+  }
+  if (engineKind == Engine::Fused) {
+    if (pbSimSetState(sim, hPos, hVel, hRad, hphase, hDead) != PB_OK) die("pbSimSetState");
+  } else {
+    copyArrayToDevice(dDead, hDead, 0, (int)(n * sizeof(int)));
+    setArray(RADII, hRad, 0, n);
+    setArray(PHASE, hphase, 0, n);
+    setArray(POSITION, hPos, 0, n);
+    setArray(VELOCITY, hVel, 0, n);
+  }
+}

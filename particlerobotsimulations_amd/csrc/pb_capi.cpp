@@ -1,0 +1,240 @@
+// pb_capi.cpp -- C wrappers around the C++ host side (class Particlebot + .cfg loader) so that
+// scripts and tests can drive it through ctypes.  Exported from libparticlebot_host.so.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "particlebot.h"
+#include "pb_config.hpp"
+
+extern "C" {
+
+// flat, pointer-free view of a resolved configuration (for inspection from scripts)
+struct pbFlatConfig {
+  uint32_t gridSizeX, gridSizeY, numCells;
+  float worldOriginX, worldOriginY, cellSizeX, cellSizeY;
+  uint32_t nCells;
+  int32_t nDead;
+  float gravity, spring, damping, shear, attraction, boundaryDamping, friction;
+  float massFactor, frictionFactor, radFactor, attractionFactor;
+  float constraint, constraint_contraction;
+  int32_t centroid_steps;
+  float centroid_int, centroid_radius;
+  float light_x, light_y, phase_update_interval;
+  int32_t control, config;
+  float min_radius, max_radius, rise_period, freq;
+  int32_t nobstacles;
+  float x1obs[PB_MAX_OBSTACLES], x2obs[PB_MAX_OBSTACLES], y1obs[PB_MAX_OBSTACLES], y2obs[PB_MAX_OBSTACLES];
+  int32_t n_cir_obstacles;
+  float x_cir_obs[PB_MAX_OBSTACLES], y_cir_obs[PB_MAX_OBSTACLES], r_cir_obs[PB_MAX_OBSTACLES];
+  int32_t Nx;
+  float phase_std;
+  uint32_t seed;
+  uint32_t light_shadow, testing, constrained_contraction, display_shadow;
+  float time_to_dead, max_time;
+  float timestep, sort_interval, dump_interval;
+  float camera_x, camera_y, light_radius;
+  int32_t display_interval, video_interval;
+  char csv_filename[300];
+  char video_filename[300];
+  float wallHalf;
+};
+
+}  // extern "C"
+
+namespace {
+
+// overrides: "name\nvalue\nname\nvalue..." applied after the file, through the same setParam
+void applyOverrides(PbRunConfig &cfg, const char *overrides) {
+  if (!overrides) return;
+  std::string s(overrides);
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t e1 = s.find('\n', pos);
+    if (e1 == std::string::npos) break;
+    size_t e2 = s.find('\n', e1 + 1);
+    if (e2 == std::string::npos) e2 = s.size();
+    cfg.setParam(s.substr(pos, e1 - pos), s.substr(e1 + 1, e2 - e1 - 1));
+    pos = e2 + 1;
+  }
+}
+
+void flatten(const PbRunConfig &cfg, pbFlatConfig *o) {
+  memset(o, 0, sizeof(*o));
+  const SimParams &p = cfg.params;
+  o->gridSizeX = p.gridSize.x;
+  o->gridSizeY = p.gridSize.y;
+  o->numCells = p.numCells;
+  o->worldOriginX = p.worldOrigin.x;
+  o->worldOriginY = p.worldOrigin.y;
+  o->cellSizeX = p.cellSize.x;
+  o->cellSizeY = p.cellSize.y;
+  o->nCells = p.nCells;
+  o->nDead = p.nDead;
+  o->gravity = p.gravity;
+  o->spring = p.spring;
+  o->damping = p.damping;
+  o->shear = p.shear;
+  o->attraction = p.attraction;
+  o->boundaryDamping = p.boundaryDamping;
+  o->friction = p.friction;
+  o->massFactor = p.massFactor;
+  o->frictionFactor = p.frictionFactor;
+  o->radFactor = p.radFactor;
+  o->attractionFactor = p.attractionFactor;
+  o->constraint = p.constraint;
+  o->constraint_contraction = p.constraint_contraction;
+  o->centroid_steps = p.centroid_steps;
+  o->centroid_int = p.centroid_int;
+  o->centroid_radius = p.centroid_radius;
+  o->light_x = p.light_x;
+  o->light_y = p.light_y;
+  o->phase_update_interval = p.phase_update_interval;
+  o->control = (int32_t)p.control;
+  o->config = (int32_t)p.config;
+  o->min_radius = p.min_radius;
+  o->max_radius = p.max_radius;
+  o->rise_period = p.rise_period;
+  o->freq = p.freq;
+  o->nobstacles = p.nobstacles;
+  o->n_cir_obstacles = p.n_cir_obstacles;
+  for (int i = 0; i < PB_MAX_OBSTACLES; i++) {
+    if (i < p.nobstacles && i < (int)cfg.x1obs.size()) {
+      o->x1obs[i] = cfg.x1obs[i];
+      o->x2obs[i] = cfg.x2obs[i];
+      o->y1obs[i] = cfg.y1obs[i];
+      o->y2obs[i] = cfg.y2obs[i];
+    }
+    if (i < p.n_cir_obstacles && i < (int)cfg.x_cir_obs.size()) {
+      o->x_cir_obs[i] = cfg.x_cir_obs[i];
+      o->y_cir_obs[i] = cfg.y_cir_obs[i];
+      o->r_cir_obs[i] = cfg.r_cir_obs[i];
+    }
+  }
+  o->Nx = p.Nx;
+  o->phase_std = p.phase_std;
+  o->seed = p.seed;
+  o->light_shadow = p.light_shadow;
+  o->testing = p.testing;
+  o->constrained_contraction = p.constrained_contraction;
+  o->display_shadow = p.display_shadow;
+  o->time_to_dead = p.time_to_dead;
+  o->max_time = p.max_time;
+  o->timestep = cfg.timestep;
+  o->sort_interval = cfg.sort_interval;
+  o->dump_interval = cfg.dump_interval;
+  o->camera_x = cfg.camera_x;
+  o->camera_y = cfg.camera_y;
+  o->light_radius = cfg.light_radius;
+  o->display_interval = cfg.display_interval;
+  o->video_interval = cfg.video_interval;
+  snprintf(o->csv_filename, sizeof(o->csv_filename), "%s", cfg.csv_filename.c_str());
+  snprintf(o->video_filename, sizeof(o->video_filename), "%s", cfg.video_filename.c_str());
+  o->wallHalf = cfg.wallHalf();
+}
+
+struct HostSim {
+  PbRunConfig cfg;
+  Particlebot *bot = nullptr;
+};
+
+}  // namespace
+
+extern "C" {
+
+// Resolve a configuration exactly as main() does (defaults, file, overrides, derived values).
+// cfg_path may be NULL (defaults only).  Returns 0, or -1 if the file cannot be opened.
+int pbHostLoadConfig(const char *cfg_path, const char *overrides, pbFlatConfig *out) {
+  PbRunConfig cfg;
+  cfg.params.seed = 0;
+  if (cfg_path && !cfg.loadFile(cfg_path)) return -1;
+  applyOverrides(cfg, overrides);
+  cfg.derive();
+  flatten(cfg, out);
+  return 0;
+}
+
+// main.cpp:913-952 without GL: load, srand(seed), construct.  engine: 0 fused, 1 legacy.
+void *pbHostCreate(const char *cfg_path, const char *overrides, int engine) {
+  HostSim *h = new HostSim();
+  h->cfg.params.seed = 0;
+  if (cfg_path && !h->cfg.loadFile(cfg_path)) {
+    delete h;
+    return nullptr;
+  }
+  applyOverrides(h->cfg, overrides);
+  h->cfg.derive();
+  srand(h->cfg.params.seed);  // main.cpp:929
+  h->bot = new Particlebot(h->cfg.params, engine ? Particlebot::Engine::Legacy : Particlebot::Engine::Fused,
+                           h->cfg.wallHalf());
+  h->bot->setExitOnMaxTime(false);
+  return h;
+}
+
+void pbHostDestroy(void *hv) {
+  HostSim *h = (HostSim *)hv;
+  if (!h) return;
+  delete h->bot;
+  delete h;
+}
+
+void pbHostReset(void *hv) { ((HostSim *)hv)->bot->reset(); }
+
+void pbHostUpdate(void *hv) {
+  HostSim *h = (HostSim *)hv;
+  h->bot->update(h->cfg.timestep, h->cfg.sort_interval);
+}
+
+int pbHostAdvance(void *hv, int nsteps) {
+  HostSim *h = (HostSim *)hv;
+  return h->bot->advance(h->cfg.timestep, h->cfg.sort_interval, nsteps);
+}
+
+float pbHostTime(void *hv) { return ((HostSim *)hv)->bot->getTime(); }
+int pbHostFinished(void *hv) { return ((HostSim *)hv)->bot->finished() ? 1 : 0; }
+
+// display()'s `dumpParticlebot(0, nCells, fp, dump_interval, testing, light)` (main.cpp:360)
+int pbHostDump(void *hv, const char *path, const char *mode) {
+  HostSim *h = (HostSim *)hv;
+  FILE *fp = fopen(path, mode);
+  if (!fp) return -1;
+  const SimParams &p = h->bot->getParams();
+  h->bot->dumpParticlebot(0, p.nCells, fp, h->cfg.dump_interval, p.testing, p.light_x, p.light_y);
+  fclose(fp);
+  return 0;
+}
+
+int pbHostLoadFromFile(void *hv, const char *path) {
+  HostSim *h = (HostSim *)hv;
+  FILE *fp = fopen(path, "r");
+  if (!fp) return -1;
+  h->bot->loadFromFile(0, h->bot->getParams().nCells, fp, h->cfg.dump_interval);
+  fclose(fp);
+  return 0;
+}
+
+// which: 0 POSITION (2n floats) 1 VELOCITY (2n) 2 RADII (n) 3 PHASE (n) 5 DEAD (n ints)
+int pbHostGetArray(void *hv, int which, void *out) {
+  HostSim *h = (HostSim *)hv;
+  const size_t n = h->bot->getParams().nCells;
+  switch (which) {
+    case 0: memcpy(out, h->bot->getArray(POSITION), 8 * n); return 0;
+    case 1: memcpy(out, h->bot->getArray(VELOCITY), 8 * n); return 0;
+    case 2: memcpy(out, h->bot->getArray(RADII), 4 * n); return 0;
+    case 3: memcpy(out, h->bot->getArray(PHASE), 4 * n); return 0;
+    case 5: memcpy(out, h->bot->getDeadArray(), 4 * n); return 0;
+    default: return -1;
+  }
+}
+
+int pbHostSetArray(void *hv, int which, const float *data, int start, int count) {
+  HostSim *h = (HostSim *)hv;
+  if (which < 0 || which > 4) return -1;
+  h->bot->setArray((ParticlebotArray)which, data, start, count);
+  return 0;
+}
+
+unsigned pbHostNumBots(void *hv) { return ((HostSim *)hv)->bot->getParams().nCells; }
+
+}  // extern "C"

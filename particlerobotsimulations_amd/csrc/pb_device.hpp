@@ -1,0 +1,478 @@
+// pb_device.hpp -- device-side parameter block and per-bot physics for gfx950.
+//
+// Arithmetic contract (DESIGN.md "Numerics"): fp32, IEEE division and sqrt (hipcc's default
+// correctly-rounded forms), NO FMA contraction (-ffp-contract=off), operation order exactly as the
+// reference writes it, with  powf(x,2)/__powf(x,2) -> x*x  and  powf(x,0.5f) -> sqrtf(x).
+// The CPU oracle follows the same rules, so the two agree bit for bit.
+//
+// Reference: particlebot_kernel_impl.cuh (cited per function).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "particlebot_kernel.h"
+
+// Flattened copy of SimParams that travels to kernels BY VALUE (kernarg segment -> SGPRs); one per
+// simulation, so many simulations can live in one process (the reference keeps a single
+// `__constant__ SimParams params`, particlebot_kernel_impl.cuh:27).
+struct PbDevParams {
+  uint32_t gridX, gridY, numCells;
+  float originX, originY, cellX, cellY;
+  uint32_t nCells;
+  int32_t nDead;
+  float gravity, spring, damping, shear, attraction, boundaryDamping, friction;
+  float massFactor, frictionFactor, attractionFactor;
+  float constraint, constraint_contraction;
+  float light_x, light_y;
+  float min_radius, max_radius, rise_period;
+  int32_t Nx;
+  uint32_t light_shadow, constrained_contraction, seed;
+  float wallHalf;
+  int32_t nobstacles;
+  float x1obs[PB_MAX_OBSTACLES], x2obs[PB_MAX_OBSTACLES], y1obs[PB_MAX_OBSTACLES], y2obs[PB_MAX_OBSTACLES];
+  int32_t n_cir;
+  float xc[PB_MAX_OBSTACLES], yc[PB_MAX_OBSTACLES], rc[PB_MAX_OBSTACLES];
+};
+
+static inline void pbFlattenParams(PbDevParams &d, const SimParams &p, float wallHalf) {
+  d.gridX = p.gridSize.x;
+  d.gridY = p.gridSize.y;
+  d.numCells = p.numCells;
+  d.originX = p.worldOrigin.x;
+  d.originY = p.worldOrigin.y;
+  d.cellX = p.cellSize.x;
+  d.cellY = p.cellSize.y;
+  d.nCells = p.nCells;
+  d.nDead = p.nDead;
+  d.gravity = p.gravity;
+  d.spring = p.spring;
+  d.damping = p.damping;
+  d.shear = p.shear;
+  d.attraction = p.attraction;
+  d.boundaryDamping = p.boundaryDamping;
+  d.friction = p.friction;
+  d.massFactor = p.massFactor;
+  d.frictionFactor = p.frictionFactor;
+  d.attractionFactor = p.attractionFactor;
+  d.constraint = p.constraint;
+  d.constraint_contraction = p.constraint_contraction;
+  d.light_x = p.light_x;
+  d.light_y = p.light_y;
+  d.min_radius = p.min_radius;
+  d.max_radius = p.max_radius;
+  d.rise_period = p.rise_period;
+  d.Nx = p.Nx;
+  d.light_shadow = p.light_shadow;
+  d.constrained_contraction = p.constrained_contraction;
+  d.seed = p.seed;
+  d.wallHalf = wallHalf > 0.0f ? wallHalf : 64.0f;
+  d.nobstacles = p.nobstacles < 0 ? 0 : (p.nobstacles > PB_MAX_OBSTACLES ? PB_MAX_OBSTACLES : p.nobstacles);
+  d.n_cir = p.n_cir_obstacles < 0 ? 0
+                                  : (p.n_cir_obstacles > PB_MAX_OBSTACLES ? PB_MAX_OBSTACLES : p.n_cir_obstacles);
+  for (int i = 0; i < PB_MAX_OBSTACLES; i++) {
+    const bool r = i < d.nobstacles;
+    d.x1obs[i] = (r && p.x1obs) ? p.x1obs[i] : 0.0f;
+    d.x2obs[i] = (r && p.x2obs) ? p.x2obs[i] : 0.0f;
+    d.y1obs[i] = (r && p.y1obs) ? p.y1obs[i] : 0.0f;
+    d.y2obs[i] = (r && p.y2obs) ? p.y2obs[i] : 0.0f;
+    const bool c = i < d.n_cir;
+    d.xc[i] = (c && p.x_cir_obs) ? p.x_cir_obs[i] : 0.0f;
+    d.yc[i] = (c && p.y_cir_obs) ? p.y_cir_obs[i] : 0.0f;
+    d.rc[i] = (c && p.r_cir_obs) ? p.r_cir_obs[i] : 0.0f;
+  }
+}
+
+// the layout scripts and reference-built callers rely on (particlebot_kernel.cuh:58-120)
+#include <cstddef>
+// (float2/uint2 are 8-byte aligned in HIP exactly as in CUDA, hence the hole after numCells)
+static_assert(offsetof(SimParams, worldOrigin) == 16 && offsetof(SimParams, nCells) == 32 &&
+                  offsetof(SimParams, nobstacles) == 144 && offsetof(SimParams, x1obs) == 152 &&
+                  offsetof(SimParams, Nx) == 216 && offsetof(SimParams, max_time) == 248 &&
+                  sizeof(SimParams) == 256,
+              "SimParams layout drifted from the reference struct");
+
+#define PB_DEV __device__ __forceinline__
+
+// helper_math.h:1244/1287 semantics: dot = ax*bx + ay*by (two roundings), length = sqrtf(dot)
+PB_DEV float pbDot(float ax, float ay, float bx, float by) { return ax * bx + ay * by; }
+PB_DEV float pbLen(float x, float y) { return sqrtf(pbDot(x, y, x, y)); }
+
+// ---- grid (impl.cuh:106-120) ---------------------------------------------------------------
+PB_DEV int pbCellX(const PbDevParams &P, float x) { return (int)floorf((x - P.originX) / P.cellX); }
+PB_DEV int pbCellY(const PbDevParams &P, float y) { return (int)floorf((y - P.originY) / P.cellY); }
+PB_DEV uint32_t pbHash(const PbDevParams &P, int gx, int gy) {
+  return ((uint32_t)gy & (P.gridY - 1u)) * P.gridX + ((uint32_t)gx & (P.gridX - 1u));
+}
+
+// ---- integration with wall clamp (impl.cuh:53-103) -------------------------------------------
+PB_DEV void pbIntegrate(const PbDevParams &P, float &px, float &py, float &vx, float &vy, float rad,
+                        float dt) {
+  const float W = P.wallHalf;
+  px = px + vx * dt;
+  py = py + vy * dt;
+  if (px > W - rad) {
+    px = W - rad;
+    vx *= P.boundaryDamping;
+  }
+  if (px < -W + rad) {
+    px = -W + rad;
+    vx *= P.boundaryDamping;
+  }
+  if (py > W - rad) {
+    py = W - rad;
+    vy *= P.boundaryDamping;
+  }
+  if (py < -W + rad) {
+    py = -W + rad;
+    vy *= P.boundaryDamping;
+  }
+}
+
+// ---- radius actuation (impl.cuh:124-181).  Returns the new radius. ---------------------------
+PB_DEV float pbActuate(const PbDevParams &P, float rad, float phase, int dead, float absA, float absR,
+                       float time, float dt) {
+  if (dead) return rad;
+  if (phase > 10000000.0f) return rad;
+  float t1 = time + phase;
+  const float period = (P.Nx + 1) * P.rise_period;
+  if (t1 < 0) t1 = t1 + 100 * (P.Nx + 1) * P.rise_period;
+  if (t1 >= period) t1 = t1 - period * floorf(t1 / period);
+  if (t1 >= 2 * P.rise_period) return rad;
+  float target;
+  if (t1 <= P.rise_period)
+    target = P.min_radius + (P.max_radius - P.min_radius) / P.rise_period * t1;
+  else
+    target = P.max_radius + (P.min_radius - P.max_radius) / P.rise_period * (t1 - P.rise_period);
+  const float want = target - rad;
+  float dr = 0;
+  const float max_speed = 0.1f;
+  float torque = want * P.constraint * rad / max_speed / P.max_radius / dt;
+  torque = fminf(torque, P.constraint);
+  if (want > 0) {
+    if (torque / rad > absR) dr = max_speed * P.max_radius / P.constraint * (torque / rad - absR) * dt;
+  } else {
+    if (P.constrained_contraction) {
+      if (-P.constraint_contraction * want > absA * rad)
+        dr = (P.constraint_contraction * want + absA * rad) / (P.constraint_contraction);
+      dr = fmaxf(dr, -P.max_radius * dt);
+    } else {
+      dr = want;
+    }
+  }
+  float r = rad + dr;
+  if (r > P.max_radius) r = P.max_radius;
+  if (r < P.min_radius) r = P.min_radius;
+  return r;
+}
+
+// ---- pair force (impl.cuh:541-594).  B's velocity is fetched lazily (contact only). ----------
+struct PbForce {
+  float fx, fy, fa, fr;
+};
+
+template <class VelFetch>
+PB_DEV void pbPair(const PbDevParams &P, float ax, float ay, float avx, float avy, float ra, float bx,
+                   float by, float rb, float attraction, VelFetch velB, PbForce &F) {
+  const float rx = bx - ax, ry = by - ay;
+  const float dist = pbLen(rx, ry);
+  const float reach = ra + rb;
+  float tx = 0.0f, ty = 0.0f;
+  if (dist < reach) {
+    const float2 vb = velB();
+    const float nx = rx / dist, ny = ry / dist;
+    const float rvx = vb.x - avx, rvy = vb.y - avy;
+    const float vn = pbDot(rvx, rvy, nx, ny);
+    const float tvx = rvx - vn * nx, tvy = rvy - vn * ny;
+    const float ks = -P.spring * (reach - dist);
+    tx += ks * nx;
+    ty += ks * ny;
+    tx += P.damping * rvx;
+    ty += P.damping * rvy;
+    tx += P.shear * tvx;
+    ty += P.shear * tvy;
+    F.fx += tx;
+    F.fy += ty;
+    F.fr += pbLen(tx, ty);
+  } else {
+    const float near1 = 0.0009f, near2 = 0.0019f, fmin_attr = 2.5f;
+    const float gap = dist - reach;
+    if (gap < near1) {
+      tx += fmin_attr * (rx / dist);
+      ty += fmin_attr * (ry / dist);
+    } else if (gap < near2) {
+      const float c = fmin_attr + (attraction / (near2 * near2) - fmin_attr) / (near2 - near1) * (gap - near1);
+      tx += c * (rx / dist);
+      ty += c * (ry / dist);
+    } else {
+      const float g2 = gap * gap;
+      tx += attraction * (rx / dist) / g2;
+      ty += attraction * (ry / dist) / g2;
+    }
+    F.fx += tx;
+    F.fy += ty;
+    F.fa += pbLen(tx, ty);
+  }
+}
+
+// common tail of obstacle contacts (impl.cuh:711-726 and :781-797): spring term (sx,sy) along the
+// contact normal (dx,dy), dashpot and shear against the bot's own velocity
+PB_DEV void pbObstacleTail(const PbDevParams &P, float vx, float vy, float dx, float dy, float sx, float sy,
+                           PbForce &F) {
+  const float rvx = -vx, rvy = -vy;
+  const float vn = pbDot(rvx, rvy, dx, dy);
+  const float tvx = rvx - vn * dx, tvy = rvy - vn * dy;
+  float tx = 0.0f, ty = 0.0f;
+  tx += sx;
+  ty += sy;
+  tx += P.damping * rvx;
+  ty += P.damping * rvy;
+  tx += P.shear * tvx;
+  ty += P.shear * tvy;
+  F.fx += tx;
+  F.fy += ty;
+  F.fr += pbLen(tx, ty);
+}
+
+// circular (impl.cuh:703-728) and rectangular (impl.cuh:729-798) obstacles
+PB_DEV void pbObstacles(const PbDevParams &P, float px, float py, float vx, float vy, float rad, PbForce &F) {
+  for (int k = 0; k < P.n_cir; k++) {
+    const float ox = P.xc[k], oy = P.yc[k], orad = P.rc[k];
+    const float ex = px - ox, ey = py - oy;
+    const float d2 = ex * ex + ey * ey;
+    const float reach = rad + orad;
+    if (d2 < reach * reach) {
+      float dx = -px + ox, dy = -py + oy;
+      const float l = pbLen(dx, dy);
+      dx = dx / l;
+      dy = dy / l;
+      const float ks = 2.0f * P.spring * (rad + orad - sqrtf(d2));
+      pbObstacleTail(P, vx, vy, dx, dy, ks * (-dx), ks * (-dy), F);
+    }
+  }
+  float dx = 0.0f, dy = 0.0f, overlap = 0.0f;
+  for (int k = 0; k < P.nobstacles; k++) {
+    const float x1 = P.x1obs[k], x2 = P.x2obs[k], y1 = P.y1obs[k], y2 = P.y2obs[k];
+    bool hit = false;
+    if (py > y1 && py < y2) {
+      if (px > x1 - rad && px < x2 - rad) {
+        hit = true;
+        dx = 1.0f;
+        dy = 0.0f;
+        overlap = px - x1 + rad;
+      }
+      if (px < x2 + rad && px > x1 + rad) {
+        hit = true;
+        dx = -1.0f;
+        dy = 0.0f;
+        overlap = -px + x2 + rad;
+      }
+    } else if (px > x1 && px < x2) {
+      if (py > y1 - rad && py < y2 - rad) {
+        hit = true;
+        dx = 0.0f;
+        dy = 1.0f;
+        overlap = py - y1 + rad;
+      }
+      if (py < y2 + rad && py > y1 + rad) {
+        hit = true;
+        dx = 0.0f;
+        dy = -1.0f;
+        overlap = -py + y2 + rad;
+      }
+    } else {
+      // corners, first match wins, in the reference's order (x2,y2) (x1,y2) (x1,y1) (x2,y1)
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const float cx = (c == 0 || c == 3) ? x2 : x1;
+        const float cy = (c < 2) ? y2 : y1;
+        const float ex = px - cx, ey = py - cy;
+        const float d2 = ex * ex + ey * ey;
+        if (!hit && d2 < rad * rad) {
+          const float l = pbLen(ex, ey);
+          dx = -ex / l;
+          dy = -ey / l;
+          overlap = rad - sqrtf(d2);
+          hit = true;
+        }
+      }
+    }
+    if (hit) {
+      const float ks = -2.0f * P.spring * overlap;
+      pbObstacleTail(P, vx, vy, dx, dy, ks * dx, ks * dy, F);
+    }
+  }
+}
+
+// static/kinetic friction and the velocity update (impl.cuh:801-825)
+PB_DEV void pbFrictionAndKick(const PbDevParams &P, bool payload, float fx, float fy, float dt, float &vx,
+                              float &vy) {
+  float friction = P.friction;
+  float gravity = P.gravity;
+  if (payload) {
+    friction *= P.frictionFactor;
+    gravity *= P.massFactor;
+  }
+  if (pbLen(vx, vy) < 0.000001f && pbLen(fx, fy) < (2.0f * friction * gravity)) {
+    fx = 0.0f;
+    fy = 0.0f;
+  }
+  if (payload) {
+    vx = vx + fx / P.massFactor * dt;
+    vy = vy + fy / P.massFactor * dt;
+  } else {
+    vx = vx + fx * dt;
+    vy = vy + fy * dt;
+  }
+  const float fric = friction * gravity * dt;
+  const float speed = pbLen(vx, vy);
+  if (speed < fric) {
+    vx = 0.0f;
+    vy = 0.0f;
+  } else {
+    vx -= fric * (vx / speed);
+    vy -= fric * (vy / speed);
+  }
+}
+
+// ---- light shadow tests (impl.cuh:184-262) ---------------------------------------------------
+PB_DEV int pbSegHit(float x0, float y0, float x1, float y1, float x3, float y3, float x4, float y4) {
+  if (fabsf((x4 - x3) / (x1 - x0)) == fabsf((y4 - y3) / (y1 - y0))) return 0;
+  float t, t1;
+  if (fabsf(y4 - y3) > 0) {
+    t = (x3 - x0 - (y3 - y0) * (x3 - x4) / (y3 - y4)) *
+        ((y3 - y4) / ((x1 - x0) * (y3 - y4) - (y1 - y0) * (x3 - x4)));
+    if (t <= 0 || t >= 1) return 0;
+    t1 = (y3 - y0 - t * (y1 - y0)) / (y3 - y4);
+    if (t1 <= 0 || t1 >= 1) return 0;
+  } else if (fabsf(x4 - x3) > 0) {
+    t = (y3 - y0 - (x3 - x0) * (y3 - y4) / (x3 - x4)) *
+        ((x3 - x4) / ((y1 - y0) * (x3 - x4) - (x1 - x0) * (y3 - y4)));
+    if (t <= 0 || t >= 1) return 0;
+    t1 = (x3 - x0 - t * (x1 - x0)) / (x3 - x4);
+    if (t1 <= 0 || t1 >= 1) return 0;
+  } else {
+    return 0;
+  }
+  return 1;
+}
+
+PB_DEV int pbCircleHit(float lx, float ly, float px, float py, float ox, float oy, float orad) {
+  const float C1 = lx * lx + ly * ly;
+  const float C2 = px * px + py * py;
+  const float C3 = ox * ox + oy * oy;
+  const float C4 = lx * px + ly * py;
+  const float C5 = lx * ox + ly * oy;
+  const float C6 = px * ox + py * oy;
+  const float A = C1 + C2 - 2 * C4;
+  const float B = -2 * C1 + 2 * C4 + 2 * C5 - 2 * C6;
+  const float C = C1 + C3 - 2 * C5 - orad * orad;
+  const float D = B * B - 4 * A * C;
+  if (D >= 0) {
+    const float R1 = (-B + sqrtf(D)) / 2 / A;
+    const float R2 = (-B - sqrtf(D)) / 2 / A;
+    if (R1 > 0 && R1 < 1) return 1;
+    if (R2 > 0 && R2 < 1) return 1;
+  }
+  return 0;
+}
+
+PB_DEV int pbInShadow(const PbDevParams &P, float px, float py) {
+  for (int i = 0; i < P.n_cir; i++)
+    if (pbCircleHit(P.light_x, P.light_y, px, py, P.xc[i], P.yc[i], P.rc[i])) return 1;
+  for (int i = 0; i < P.nobstacles; i++) {
+    const float x1 = P.x1obs[i], x2 = P.x2obs[i], y1 = P.y1obs[i], y2 = P.y2obs[i];
+    if (pbSegHit(P.light_x, P.light_y, px, py, x1, y1, x1, y2)) return 1;
+    if (pbSegHit(P.light_x, P.light_y, px, py, x1, y2, x2, y2)) return 1;
+    if (pbSegHit(P.light_x, P.light_y, px, py, x2, y2, x2, y1)) return 1;
+    if (pbSegHit(P.light_x, P.light_y, px, py, x2, y1, x1, y1)) return 1;
+  }
+  return 0;
+}
+
+// phase from distance to the light (impl.cuh:264-290); `old` is returned when shadowed with
+// light_shadow not in {1,2}
+PB_DEV float pbPhase(const PbDevParams &P, float px, float py, float spacing, float min_d, float old) {
+  const float dist = pbLen(px - P.light_x, py - P.light_y);
+  bool visible = true;
+  if (P.light_shadow) {
+    if (pbInShadow(P, px, py)) visible = false;
+  }
+  if (!visible) {
+    float ph = old;
+    if (P.light_shadow == 1) ph = -(P.Nx - 1) * P.rise_period;
+    if (P.light_shadow == 2) ph = 9999999999.0f;
+    return ph;
+  }
+  return (min_d - dist) / (spacing)*P.rise_period;
+}
+
+// ---- PB-RNG v1: counter-based standard normal for (seed, bot, draw) ---------------------------
+// Replaces cuRAND XORWOW + curand_normal (impl.cuh:36-51), which cannot be pinned here.
+// Polynomial log / sin / cos in plain fp32 so CPU and GPU agree bit for bit.
+PB_DEV uint64_t pbMix64(uint64_t z) {
+  z ^= z >> 30;
+  z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27;
+  z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return z;
+}
+
+PB_DEV float pbNormal(uint32_t seed, uint32_t bot, uint32_t draw) {
+  uint64_t x = (((uint64_t)seed << 32) | (uint64_t)bot) + 0x9E3779B97F4A7C15ull * (uint64_t)(draw + 1u);
+  x = pbMix64(x);
+  x = pbMix64(x ^ 0xD1342543DE82EF95ull);
+  const uint32_t k1 = (uint32_t)(x >> 40) & 0xFFFFFFu;
+  const uint32_t k2 = (uint32_t)(x >> 8) & 0xFFFFFFu;
+  const uint32_t v = k1 + 1u;  // u1 = v * 2^-24 in (0,1]
+  int e = 31 - __clz((int)v);
+  float m = (float)v * __uint_as_float((uint32_t)(127 - e) << 23);  // exact, in [1,2)
+  if (m > 1.41421356f) {
+    m = m * 0.5f;
+    e += 1;
+  }
+  const float t = (m - 1.0f) / (m + 1.0f);
+  const float t2 = t * t;
+  float p = 0.111111111f;
+  p = p * t2 + 0.142857143f;
+  p = p * t2 + 0.2f;
+  p = p * t2 + 0.333333333f;
+  p = p * t2 + 1.0f;
+  const float lnu = 2.0f * t * p + (float)(e - 24) * 0.693147181f;
+  const float r = sqrtf(-2.0f * lnu);
+  const uint32_t q = k2 >> 22;
+  const float a = (float)(k2 & 0x3FFFFFu) * (1.0f / 4194304.0f) * 1.57079633f;
+  const float a2 = a * a;
+  float s = -2.50521084e-8f;
+  s = s * a2 + 2.75573192e-6f;
+  s = s * a2 - 1.98412698e-4f;
+  s = s * a2 + 8.33333333e-3f;
+  s = s * a2 - 1.66666667e-1f;
+  s = s * a2 + 1.0f;
+  s = s * a;
+  float c = 2.08767570e-9f;
+  c = c * a2 - 2.75573192e-7f;
+  c = c * a2 + 2.48015873e-5f;
+  c = c * a2 - 1.38888889e-3f;
+  c = c * a2 + 4.16666667e-2f;
+  c = c * a2 - 0.5f;
+  c = c * a2 + 1.0f;
+  const float cv = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+  return r * cv;
+}
+
+// ---- error helpers shared by the host code of every translation unit -------------------------
+#include <cstdio>
+#include <cstdlib>
+
+// legacy boundary: print + exit(EXIT_FAILURE), as include/helper_cuda.h:1000-1029 does
+#define PB_CHECK_ABORT(expr)                                                                         \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) {                                                                          \
+      fprintf(stderr, "HIP error at %s:%d code=%d(%s) \"%s\"\n", __FILE__, __LINE__, (int)e_,        \
+              hipGetErrorName(e_), #expr);                                                           \
+      exit(EXIT_FAILURE);                                                                            \
+    }                                                                                                \
+  } while (0)

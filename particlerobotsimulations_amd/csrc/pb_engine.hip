@@ -1,0 +1,689 @@
+// pb_engine.hip -- pbSim: the resident, fused particle-robot engine for MI355X (gfx950).
+//
+// Reference path: Particlebot::update (particlebot.cpp:170-300) and the kernels it launches
+// (particlebot_kernel_impl.cuh).  Same arithmetic, different shape:
+//
+//  * State lives in HBM in CELL-SORTED order between re-sorts (slot s <-> original bot orig[s]).
+//    The reference re-gathers pos/vel/rad through a stale permutation every step
+//    (reorderDataAndFindCellStartD, impl.cuh:469-538) and memsets a 1 MiB cellStart table; here
+//    the gather is the identity and the cell table changes only at a re-sort.
+//  * Cell ranges are a DENSE exclusive scan cellS[0..numCells]: cell h owns slots
+//    [cellS[h], cellS[h+1]).  With a row-major hash the 5 cells x-2..x+2 of one grid row are one
+//    contiguous slot range, so the 25-cell stencil is 5 ranges (10 table reads), visited in the
+//    reference's order (row y-2..y+2, then x, then ascending slot) => identical fp32 sums.
+//  * One kernel per timestep: k_force<FUSE> computes step n's forces and velocity kick and then,
+//    for the same bot, step n+1's radius actuation and integration, reading buffer A and writing
+//    buffer B (ping-pong), because neighbours still need the step-n positions.  Per bot it reads
+//    posrad 16 + vel 8 + phase 4 + dead 4 + absForce_r 4 B and writes posrad 16 + vel 8 +
+//    absForce 8 B; neighbour reads hit L1/L2.
+//  * Workgroup -> tile mapping is XCD-aware: the 8 XCDs each walk one contiguous eighth of the
+//    sorted array, so a tile's neighbour rows (+-2 grid rows) are in the same XCD's L2.
+//  * posrad = (x, y, radius, attraction factor): one 16-byte load per neighbour; the payload's
+//    attractionFactor (impl.cuh:629-633,640-644) rides in .w so the pair loop has no index lookups.
+#include <cstring>
+#include <string>
+
+#include "particlebot_hip.h"
+#include "pb_device.hpp"
+#include "pb_internal.hpp"
+
+namespace {
+
+thread_local std::string g_lastError;
+
+#define PB_TRY(expr)                                                                                 \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) {                                                                          \
+      g_lastError = std::string(hipGetErrorName(e_)) + " at " + __FILE__ + ":" + std::to_string(__LINE__) + \
+                    " in " #expr;                                                                    \
+      return PB_ERR_HIP;                                                                             \
+    }                                                                                                \
+  } while (0)
+
+constexpr int TILE = 256;
+
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---- kernels ------------------------------------------------------------------------------
+
+// stand-alone radius actuation + integration for one step (impl.cuh:124-181 + :53-103), in place
+__global__ __launch_bounds__(TILE) void k_state(PbDevParams P, float4 *__restrict__ pr, float2 *__restrict__ vel,
+                                                const float *__restrict__ phase, const int *__restrict__ dead,
+                                                const float *__restrict__ absA, const float *__restrict__ absR,
+                                                uint32_t n, float time, float dt, int doRadius) {
+  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
+  if (s >= n) return;
+  float4 q = pr[s];
+  float2 v = vel[s];
+  if (doRadius) q.z = pbActuate(P, q.z, phase[s], dead[s], absA[s], absR[s], time, dt);
+  pbIntegrate(P, q.x, q.y, v.x, v.y, q.z, dt);
+  pr[s] = q;
+  vel[s] = v;
+}
+
+// Forces + kick of step n (impl.cuh:657-831); with FUSE also radius + integration of step n+1.
+template <bool FUSE>
+__global__ __launch_bounds__(TILE) void k_force(PbDevParams P, const float4 *__restrict__ prIn,
+                                                const float2 *__restrict__ velIn, float4 *__restrict__ prOut,
+                                                float2 *__restrict__ velOut, const float *__restrict__ phase,
+                                                const int *__restrict__ dead, float *__restrict__ absA,
+                                                float *__restrict__ absR, const uint32_t *__restrict__ orig,
+                                                const uint32_t *__restrict__ cellS, uint32_t n, float dt,
+                                                float timeNext, int doRadiusNext) {
+  // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (round-robin dispatch); give
+  // each XCD one contiguous eighth of the tiles.  gridDim.x is a multiple of 8.
+  const uint32_t per = gridDim.x >> 3;
+  const uint32_t tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  const uint32_t s = tile * TILE + threadIdx.x;
+  if (s >= n) return;
+
+  const float4 me = prIn[s];
+  float2 v = velIn[s];
+  const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
+  const bool payloadMode = (P.nDead == -1);
+  bool selfPayload = false;
+  if (payloadMode) selfPayload = (orig[s] == P.nCells - 1u);
+  const float att1 = selfPayload ? P.attractionFactor : 1.0f;
+
+  PbForce F;
+  F.fx = 0.0f;
+  F.fy = 0.0f;
+  F.fa = 0.0f;
+  F.fr = 0.0f * absR[s];  // impl.cuh:688
+
+  const uint32_t GX = P.gridX;
+  const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
+  const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;  // cells before the x-wrap
+  const int nseg = first < 5u ? 2 : 1;
+  for (int dy = -2; dy <= 2; dy++) {
+    const uint32_t row = ((uint32_t)(gy + dy) & (P.gridY - 1u)) * GX;
+    for (int sg = 0; sg < nseg; sg++) {
+      const uint32_t c0 = sg == 0 ? mx0 : 0u;
+      const uint32_t c1 = sg == 0 ? mx0 + first : 5u - first;
+      const uint32_t lo = cellS[row + c0];
+      const uint32_t hi = cellS[row + c1];
+      for (uint32_t j = lo; j < hi; j++) {
+        if (j == s) continue;
+        const float4 q = prIn[j];
+        pbPair(P, me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, P.attraction * q.w * att1,
+               [&]() { return velIn[j]; }, F);
+      }
+    }
+  }
+  pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
+  pbFrictionAndKick(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
+
+  float4 out = me;
+  if (FUSE) {
+    if (doRadiusNext) out.z = pbActuate(P, me.z, phase[s], dead[s], F.fa, F.fr, timeNext, dt);
+    pbIntegrate(P, out.x, out.y, v.x, v.y, out.z, dt);
+  }
+  prOut[s] = out;
+  velOut[s] = v;
+  absA[s] = F.fa;
+  absR[s] = F.fr;
+}
+
+// re-sort step 1: hash in ORIGINAL order (calcHashD, impl.cuh:446-465) + inverse permutation
+__global__ __launch_bounds__(TILE) void k_hash(PbDevParams P, const float4 *__restrict__ pr,
+                                               const uint32_t *__restrict__ orig, uint32_t *__restrict__ keys,
+                                               uint32_t *__restrict__ vals, uint32_t *__restrict__ slotOf, uint32_t n) {
+  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
+  if (s >= n) return;
+  const float4 q = pr[s];
+  const uint32_t o = orig[s];
+  keys[o] = pbHash(P, pbCellX(P, q.x), pbCellY(P, q.y));
+  vals[o] = o;
+  slotOf[o] = s;
+}
+
+// re-sort step 3: move every per-bot array into the new slot order
+__global__ __launch_bounds__(TILE) void k_permute(const uint32_t *__restrict__ newOrig,
+                                                  const uint32_t *__restrict__ slotOf, const float4 *__restrict__ prIn,
+                                                  const float2 *__restrict__ velIn, const float *__restrict__ phaseIn,
+                                                  const int *__restrict__ deadIn, const float *__restrict__ absAIn,
+                                                  const float *__restrict__ absRIn, float4 *__restrict__ prOut,
+                                                  float2 *__restrict__ velOut, float *__restrict__ phaseOut,
+                                                  int *__restrict__ deadOut, float *__restrict__ absAOut,
+                                                  float *__restrict__ absROut, uint32_t *__restrict__ origOut,
+                                                  uint32_t n) {
+  const uint32_t t = blockIdx.x * TILE + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t o = newOrig[t];
+  const uint32_t src = slotOf[o];
+  prOut[t] = prIn[src];
+  velOut[t] = velIn[src];
+  phaseOut[t] = phaseIn[src];
+  deadOut[t] = deadIn[src];
+  absAOut[t] = absAIn[src];
+  absROut[t] = absRIn[src];
+  origOut[t] = o;
+}
+
+// re-sort step 4: cellS[c] = number of bots whose hash is < c (lower bound in the sorted keys)
+__global__ __launch_bounds__(TILE) void k_cell_scan(const uint32_t *__restrict__ sortedKeys, uint32_t n,
+                                                    uint32_t *__restrict__ cellS, uint32_t numCells) {
+  const uint32_t c = blockIdx.x * TILE + threadIdx.x;
+  if (c > numCells) return;
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (sortedKeys[mid] < c) lo = mid + 1;
+    else hi = mid;
+  }
+  cellS[c] = lo;
+}
+
+// min over bots of the squared distance to the light, as the host loop of particlebot.cpp:215-228
+// squares it: powf(light-x,2)+powf(light-y,2).  Non-negative floats order like their bit patterns,
+// so an integer atomicMin is exact and order-independent.
+__global__ __launch_bounds__(TILE) void k_min_dist2(PbDevParams P, const float4 *__restrict__ pr, uint32_t n,
+                                                    uint32_t *__restrict__ outBits) {
+  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
+  uint32_t bits = 0x7f800000u;  // +inf
+  if (s < n) {
+    const float4 q = pr[s];
+    const float dx = P.light_x - q.x, dy = P.light_y - q.y;
+    bits = __float_as_uint(dx * dx + dy * dy);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(bits, d, 64);
+    bits = o < bits ? o : bits;
+  }
+  if ((threadIdx.x & 63u) == 0u) atomicMin(outBits, bits);
+}
+
+// updatePhase (impl.cuh:264-290) + add_normal_noise (impl.cuh:43-51) in slot order
+__global__ __launch_bounds__(TILE) void k_phase(PbDevParams P, const float4 *__restrict__ pr,
+                                                const uint32_t *__restrict__ orig, float *__restrict__ phase,
+                                                uint32_t n, float spacing, float min_d, float std, uint32_t draw) {
+  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
+  if (s >= n) return;
+  const float4 q = pr[s];
+  float ph = pbPhase(P, q.x, q.y, spacing, min_d, phase[s]);
+  if (std != 0.0f) {
+    const float noise = std * pbNormal(P.seed, orig[s], draw);
+    ph += noise;
+  }
+  phase[s] = ph;
+}
+
+// host arrays (original order, staged on the device) -> slot order
+__global__ __launch_bounds__(TILE) void k_set_state(PbDevParams P, const uint32_t *__restrict__ orig,
+                                                    float4 *__restrict__ pr, float2 *__restrict__ vel,
+                                                    float *__restrict__ phase, int *__restrict__ dead,
+                                                    const float2 *__restrict__ inPos, const float2 *__restrict__ inVel,
+                                                    const float *__restrict__ inRad, const float *__restrict__ inPhase,
+                                                    const int *__restrict__ inDead, uint32_t n) {
+  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t o = orig[s];
+  float4 q = pr[s];
+  if (inPos) {
+    const float2 p = inPos[o];
+    q.x = p.x;
+    q.y = p.y;
+  }
+  if (inRad) q.z = inRad[o];
+  q.w = (P.nDead == -1 && o == P.nCells - 1u) ? P.attractionFactor : 1.0f;
+  pr[s] = q;
+  if (inVel) vel[s] = inVel[o];
+  if (inPhase) phase[s] = inPhase[o];
+  if (inDead) dead[s] = inDead[o];
+}
+
+// slot order -> original order
+__global__ __launch_bounds__(TILE) void k_get_state(const uint32_t *__restrict__ orig, const float4 *__restrict__ pr,
+                                                    const float2 *__restrict__ vel, const float *__restrict__ phase,
+                                                    const int *__restrict__ dead, const float *__restrict__ absA,
+                                                    const float *__restrict__ absR, float2 *__restrict__ outPos,
+                                                    float2 *__restrict__ outVel, float *__restrict__ outRad,
+                                                    float *__restrict__ outPhase, int *__restrict__ outDead,
+                                                    float *__restrict__ outAbsA, float *__restrict__ outAbsR,
+                                                    uint32_t n) {
+  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t o = orig[s];
+  const float4 q = pr[s];
+  outPos[o] = make_float2(q.x, q.y);
+  outRad[o] = q.z;
+  outVel[o] = vel[s];
+  outPhase[o] = phase[s];
+  outDead[o] = dead[s];
+  outAbsA[o] = absA[s];
+  outAbsR[o] = absR[s];
+}
+
+__global__ __launch_bounds__(TILE) void k_iota(uint32_t *__restrict__ a, uint32_t n) {
+  const uint32_t i = blockIdx.x * TILE + threadIdx.x;
+  if (i < n) a[i] = i;
+}
+
+// centre of mass in ORIGINAL index order, fixed summation tree: per-workgroup partial sums of
+// 256 consecutive bots (double), then one workgroup adds the partials in order.
+__global__ __launch_bounds__(TILE) void k_com_partial(const float2 *__restrict__ posOrig, uint32_t n,
+                                                      double2 *__restrict__ partial) {
+  __shared__ double2 sh[TILE];
+  const uint32_t i = blockIdx.x * TILE + threadIdx.x;
+  double2 v = make_double2(0.0, 0.0);
+  if (i < n) {
+    const float2 p = posOrig[i];
+    v = make_double2((double)p.x, (double)p.y);
+  }
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = TILE / 2; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      sh[threadIdx.x].x += sh[threadIdx.x + w].x;
+      sh[threadIdx.x].y += sh[threadIdx.x + w].y;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ void k_com_final(const double2 *__restrict__ partial, uint32_t nb, uint32_t n, double2 *__restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double sx = 0.0, sy = 0.0;
+  for (uint32_t b = 0; b < nb; b++) {
+    sx += partial[b].x;
+    sy += partial[b].y;
+  }
+  out[0] = make_double2(sx / (double)n, sy / (double)n);
+}
+
+}  // namespace
+
+// ---- the object -----------------------------------------------------------------------------
+
+struct pbSim {
+  PbDevParams P;
+  SimParams host;
+  uint32_t n = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  float4 *pr[2] = {nullptr, nullptr};
+  float2 *vel[2] = {nullptr, nullptr};
+  float *phase[2] = {nullptr, nullptr};
+  int *dead[2] = {nullptr, nullptr};
+  float *absA[2] = {nullptr, nullptr};
+  float *absR[2] = {nullptr, nullptr};
+  uint32_t *orig[2] = {nullptr, nullptr};
+  int cur = 0;  // which copy of every array is live
+
+  uint32_t *cellS = nullptr;
+  uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *slotOf = nullptr;
+  uint32_t *dMin = nullptr;
+  uint32_t *hMin = nullptr;  // pinned
+  char *stage = nullptr;     // 36 n bytes: pos 8n | vel 8n | rad 4n | phase 4n | dead 4n | absA 4n | absR 4n
+  double2 *comPartial = nullptr, *comOut = nullptr;
+  double2 *hCom = nullptr;  // pinned
+
+  float time = 0.0f;
+  uint32_t phaseDraws = 0;
+  bool haveCells = false;
+  bool resortEveryStep = false;
+  pbSimStats stats{};
+};
+
+namespace {
+
+inline bool gate(float t, float interval, float dt) {
+  // the reference's fp32 schedule test (particlebot.cpp:207,212,256)
+  return t - interval * floorf(t / interval) < dt;
+}
+
+int resort(pbSim *S) {
+  const uint32_t n = S->n;
+  const int c = S->cur, o = c ^ 1;
+  const dim3 g(cdiv(n, TILE)), b(TILE);
+  hipLaunchKernelGGL(k_hash, g, b, 0, S->stream, S->P, S->pr[c], S->orig[c], S->keys[0], S->vals[0], S->slotOf, n);
+  hipError_t e;
+  const int where = pbRadixSortPairs(S->keys[0], S->vals[0], S->keys[1], S->vals[1], S->hist, n,
+                                     pbKeyBits(S->P.numCells), S->stream, &e);
+  if (where < 0) PB_TRY(e);
+  hipLaunchKernelGGL(k_permute, g, b, 0, S->stream, S->vals[where], S->slotOf, S->pr[c], S->vel[c], S->phase[c],
+                     S->dead[c], S->absA[c], S->absR[c], S->pr[o], S->vel[o], S->phase[o], S->dead[o], S->absA[o],
+                     S->absR[o], S->orig[o], n);
+  hipLaunchKernelGGL(k_cell_scan, dim3(cdiv(S->P.numCells + 1u, TILE)), b, 0, S->stream, S->keys[where], n, S->cellS,
+                     S->P.numCells);
+  PB_TRY(hipGetLastError());
+  S->cur = o;
+  S->haveCells = true;
+  S->stats.resorts++;
+  return PB_OK;
+}
+
+int phaseUpdate(pbSim *S) {
+  // particlebot.cpp:212-237.  The min distance goes back to the host (4 bytes) because the
+  // reference takes its square root with glibc powf there (:219); max_d is unused by the kernel.
+  const uint32_t n = S->n;
+  const int c = S->cur;
+  const dim3 g(cdiv(n, TILE)), b(TILE);
+  PB_TRY(hipMemsetAsync(S->dMin, 0xff, sizeof(uint32_t), S->stream));
+  hipLaunchKernelGGL(k_min_dist2, g, b, 0, S->stream, S->P, S->pr[c], n, S->dMin);
+  PB_TRY(hipMemcpyAsync(S->hMin, S->dMin, sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream));
+  PB_TRY(hipStreamSynchronize(S->stream));
+  float minD2;
+  memcpy(&minD2, S->hMin, sizeof(float));
+  const float min_d = powf(minD2, 0.5f);
+  const float spacing = 2.0f * S->host.min_radius;
+  const float std = S->host.phase_std;
+  hipLaunchKernelGGL(k_phase, g, b, 0, S->stream, S->P, S->pr[c], S->orig[c], S->phase[c], n, spacing, min_d, std,
+                     S->phaseDraws);
+  PB_TRY(hipGetLastError());
+  if (std != 0.0f) S->phaseDraws++;
+  S->stats.phase_updates++;
+  return PB_OK;
+}
+
+int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
+  const uint32_t n = S->n;
+  const dim3 gA(cdiv(n, TILE)), b(TILE);
+  const dim3 gF(cdiv(cdiv(n, TILE), 8) * 8);
+  const float pui = S->host.phase_update_interval;
+  const bool lightWave = (S->host.control == LIGHT_WAVE);
+  bool ahead = false;  // true: radius+integration of the coming step are already applied
+  int k = 0;
+  for (; k < nsteps; k++) {
+    const float t = S->time;
+    if (t > S->host.max_time) break;  // particlebot.cpp:174-176 (the reference exits the process)
+    if (!ahead) {
+      if (lightWave && gate(t, pui, dt)) {
+        const int rc = phaseUpdate(S);
+        if (rc) return rc;
+      }
+      const int c = S->cur;
+      hipLaunchKernelGGL(k_state, gA, b, 0, S->stream, S->P, S->pr[c], S->vel[c], S->phase[c], S->dead[c],
+                         S->absA[c], S->absR[c], n, t, dt, (int)(lightWave && t >= 0));
+      S->stats.state_launches++;
+    }
+    if (S->resortEveryStep || !S->haveCells || gate(t, sortInterval, dt)) {
+      const int rc = resort(S);
+      if (rc) return rc;
+    }
+    const float tNext = t + dt;
+    // Fuse the next step's radius+integration unless this is the last step of the batch or the
+    // next step will not run.  A phase update due at the start of the next step only needs the
+    // positions of THIS step's integration, which are final now, so it runs before the launch.
+    const bool fuse = (k + 1 < nsteps) && !(tNext > S->host.max_time);
+    if (fuse && lightWave && gate(tNext, pui, dt)) {
+      const int rc = phaseUpdate(S);
+      if (rc) return rc;
+    }
+    const int c = S->cur, o = c ^ 1;
+    if (fuse) {
+      hipLaunchKernelGGL(k_force<true>, gF, b, 0, S->stream, S->P, S->pr[c], S->vel[c], S->pr[o], S->vel[o],
+                         S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c], S->cellS, n, dt, tNext,
+                         (int)(lightWave && tNext >= 0));
+      S->stats.fused_launches++;
+    } else {
+      hipLaunchKernelGGL(k_force<false>, gF, b, 0, S->stream, S->P, S->pr[c], S->vel[c], S->pr[o], S->vel[o],
+                         S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c], S->cellS, n, dt, tNext, 0);
+      S->stats.plain_launches++;
+    }
+    // pr/vel moved to the other copy; the remaining arrays did not.  Swap just those two.
+    {
+      float4 *tp = S->pr[c];
+      S->pr[c] = S->pr[o];
+      S->pr[o] = tp;
+      float2 *tv = S->vel[c];
+      S->vel[c] = S->vel[o];
+      S->vel[o] = tv;
+    }
+    S->time = tNext;
+    S->stats.steps++;
+    ahead = fuse;
+  }
+  PB_TRY(hipGetLastError());
+  if (done) *done = k;
+  return PB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pbGetLastErrorString(void) { return g_lastError.c_str(); }
+
+void pbSimDestroy(pbSim *S) {
+  if (!S) return;
+  if (S->stream) (void)hipStreamSynchronize(S->stream);
+  for (int i = 0; i < 2; i++) {
+    (void)hipFree(S->pr[i]);
+    (void)hipFree(S->vel[i]);
+    (void)hipFree(S->phase[i]);
+    (void)hipFree(S->dead[i]);
+    (void)hipFree(S->absA[i]);
+    (void)hipFree(S->absR[i]);
+    (void)hipFree(S->orig[i]);
+    (void)hipFree(S->keys[i]);
+    (void)hipFree(S->vals[i]);
+  }
+  (void)hipFree(S->cellS);
+  (void)hipFree(S->hist);
+  (void)hipFree(S->slotOf);
+  (void)hipFree(S->dMin);
+  (void)hipFree(S->stage);
+  (void)hipFree(S->comPartial);
+  (void)hipFree(S->comOut);
+  if (S->hMin) (void)hipHostFree(S->hMin);
+  if (S->hCom) (void)hipHostFree(S->hCom);
+  if (S->ev0) (void)hipEventDestroy(S->ev0);
+  if (S->ev1) (void)hipEventDestroy(S->ev1);
+  if (S->stream) (void)hipStreamDestroy(S->stream);
+  delete S;
+}
+
+int pbSimCreate(pbSim **out, const SimParams *params, float wallHalf) {
+  if (!out || !params) {
+    g_lastError = "pbSimCreate: null argument";
+    return PB_ERR_ARG;
+  }
+  *out = nullptr;
+  const uint32_t gx = params->gridSize.x, gy = params->gridSize.y;
+  if (gx < 8 || gy < 8 || (gx & (gx - 1)) || (gy & (gy - 1)) || params->numCells != gx * gy) {
+    g_lastError = "pbSimCreate: gridSize must be a power of two >= 8 per axis and numCells = x*y";
+    return PB_ERR_ARG;
+  }
+  if (params->nCells == 0) {
+    g_lastError = "pbSimCreate: nCells must be > 0";
+    return PB_ERR_ARG;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    g_lastError = "pbSimCreate: no HIP device visible";
+    return PB_ERR_NO_DEVICE;
+  }
+  pbSim *S = new pbSim();
+  S->host = *params;
+  S->host.x1obs = S->host.x2obs = S->host.y1obs = S->host.y2obs = nullptr;
+  S->host.x_cir_obs = S->host.y_cir_obs = S->host.r_cir_obs = nullptr;
+  pbFlattenParams(S->P, *params, wallHalf);
+  S->n = params->nCells;
+  const size_t n = S->n;
+#define PB_TRY_NEW(expr)            \
+  do {                              \
+    hipError_t e_ = (expr);         \
+    if (e_ != hipSuccess) {         \
+      g_lastError = std::string(hipGetErrorName(e_)) + " in " #expr; \
+      pbSimDestroy(S);              \
+      return PB_ERR_HIP;            \
+    }                               \
+  } while (0)
+  PB_TRY_NEW(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
+  PB_TRY_NEW(hipEventCreate(&S->ev0));
+  PB_TRY_NEW(hipEventCreate(&S->ev1));
+  for (int i = 0; i < 2; i++) {
+    PB_TRY_NEW(hipMalloc((void **)&S->pr[i], sizeof(float4) * n));
+    PB_TRY_NEW(hipMalloc((void **)&S->vel[i], sizeof(float2) * n));
+    PB_TRY_NEW(hipMalloc((void **)&S->phase[i], sizeof(float) * n));
+    PB_TRY_NEW(hipMalloc((void **)&S->dead[i], sizeof(int) * n));
+    PB_TRY_NEW(hipMalloc((void **)&S->absA[i], sizeof(float) * n));
+    PB_TRY_NEW(hipMalloc((void **)&S->absR[i], sizeof(float) * n));
+    PB_TRY_NEW(hipMalloc((void **)&S->orig[i], sizeof(uint32_t) * n));
+    PB_TRY_NEW(hipMalloc((void **)&S->keys[i], sizeof(uint32_t) * n));
+    PB_TRY_NEW(hipMalloc((void **)&S->vals[i], sizeof(uint32_t) * n));
+    PB_TRY_NEW(hipMemsetAsync(S->pr[i], 0, sizeof(float4) * n, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->vel[i], 0, sizeof(float2) * n, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->phase[i], 0, sizeof(float) * n, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->dead[i], 0, sizeof(int) * n, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->absA[i], 0, sizeof(float) * n, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->absR[i], 0, sizeof(float) * n, S->stream));
+  }
+  PB_TRY_NEW(hipMalloc((void **)&S->cellS, sizeof(uint32_t) * ((size_t)S->P.numCells + 1)));
+  PB_TRY_NEW(hipMalloc((void **)&S->hist, sizeof(uint32_t) * pbSortHistEntries(S->n)));
+  PB_TRY_NEW(hipMalloc((void **)&S->slotOf, sizeof(uint32_t) * n));
+  PB_TRY_NEW(hipMalloc((void **)&S->dMin, sizeof(uint32_t)));
+  PB_TRY_NEW(hipMalloc((void **)&S->stage, 36 * n));
+  PB_TRY_NEW(hipMalloc((void **)&S->comPartial, sizeof(double2) * cdiv(S->n, TILE)));
+  PB_TRY_NEW(hipMalloc((void **)&S->comOut, sizeof(double2)));
+  PB_TRY_NEW(hipHostMalloc((void **)&S->hMin, sizeof(uint32_t)));
+  PB_TRY_NEW(hipHostMalloc((void **)&S->hCom, sizeof(double2)));
+  hipLaunchKernelGGL(k_iota, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->orig[0], S->n);
+  // attraction factor column and a defined radius for every slot
+  hipLaunchKernelGGL(k_set_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->P, S->orig[0], S->pr[0],
+                     S->vel[0], S->phase[0], S->dead[0], (const float2 *)nullptr, (const float2 *)nullptr,
+                     (const float *)nullptr, (const float *)nullptr, (const int *)nullptr, S->n);
+  PB_TRY_NEW(hipGetLastError());
+  PB_TRY_NEW(hipStreamSynchronize(S->stream));
+#undef PB_TRY_NEW
+  *out = S;
+  return PB_OK;
+}
+
+int pbSimSetState(pbSim *S, const float *pos, const float *vel, const float *rad, const float *phase,
+                  const int *dead) {
+  if (!S) return PB_ERR_ARG;
+  const size_t n = S->n;
+  char *st = S->stage;
+  float2 *dPos = (float2 *)st, *dVel = (float2 *)(st + 8 * n);
+  float *dRad = (float *)(st + 16 * n), *dPhase = (float *)(st + 20 * n);
+  int *dDead = (int *)(st + 24 * n);
+  if (pos) PB_TRY(hipMemcpyAsync(dPos, pos, 8 * n, hipMemcpyHostToDevice, S->stream));
+  if (vel) PB_TRY(hipMemcpyAsync(dVel, vel, 8 * n, hipMemcpyHostToDevice, S->stream));
+  if (rad) PB_TRY(hipMemcpyAsync(dRad, rad, 4 * n, hipMemcpyHostToDevice, S->stream));
+  if (phase) PB_TRY(hipMemcpyAsync(dPhase, phase, 4 * n, hipMemcpyHostToDevice, S->stream));
+  if (dead) PB_TRY(hipMemcpyAsync(dDead, dead, 4 * n, hipMemcpyHostToDevice, S->stream));
+  const int c = S->cur;
+  hipLaunchKernelGGL(k_set_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->P, S->orig[c], S->pr[c],
+                     S->vel[c], S->phase[c], S->dead[c], pos ? dPos : nullptr, vel ? dVel : nullptr,
+                     rad ? dRad : nullptr, phase ? dPhase : nullptr, dead ? dDead : nullptr, S->n);
+  PB_TRY(hipGetLastError());
+  PB_TRY(hipStreamSynchronize(S->stream));
+  return PB_OK;
+}
+
+static int gatherToStage(pbSim *S) {
+  const size_t n = S->n;
+  char *st = S->stage;
+  const int c = S->cur;
+  hipLaunchKernelGGL(k_get_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->orig[c], S->pr[c], S->vel[c],
+                     S->phase[c], S->dead[c], S->absA[c], S->absR[c], (float2 *)st, (float2 *)(st + 8 * n),
+                     (float *)(st + 16 * n), (float *)(st + 20 * n), (int *)(st + 24 * n), (float *)(st + 28 * n),
+                     (float *)(st + 32 * n), S->n);
+  PB_TRY(hipGetLastError());
+  return PB_OK;
+}
+
+int pbSimGetState(pbSim *S, float *pos, float *vel, float *rad, float *phase, int *dead, float *absForce_a,
+                  float *absForce_r) {
+  if (!S) return PB_ERR_ARG;
+  const size_t n = S->n;
+  char *st = S->stage;
+  const int rc = gatherToStage(S);
+  if (rc) return rc;
+  if (pos) PB_TRY(hipMemcpyAsync(pos, st, 8 * n, hipMemcpyDeviceToHost, S->stream));
+  if (vel) PB_TRY(hipMemcpyAsync(vel, st + 8 * n, 8 * n, hipMemcpyDeviceToHost, S->stream));
+  if (rad) PB_TRY(hipMemcpyAsync(rad, st + 16 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
+  if (phase) PB_TRY(hipMemcpyAsync(phase, st + 20 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
+  if (dead) PB_TRY(hipMemcpyAsync(dead, st + 24 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
+  if (absForce_a) PB_TRY(hipMemcpyAsync(absForce_a, st + 28 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
+  if (absForce_r) PB_TRY(hipMemcpyAsync(absForce_r, st + 32 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
+  PB_TRY(hipStreamSynchronize(S->stream));
+  return PB_OK;
+}
+
+int pbSimSetTime(pbSim *S, float time) {
+  if (!S) return PB_ERR_ARG;
+  S->time = time;
+  return PB_OK;
+}
+
+int pbSimGetTime(pbSim *S, float *time) {
+  if (!S || !time) return PB_ERR_ARG;
+  *time = S->time;
+  return PB_OK;
+}
+
+int pbSimGetPhaseDraws(pbSim *S, unsigned *draws) {
+  if (!S || !draws) return PB_ERR_ARG;
+  *draws = S->phaseDraws;
+  return PB_OK;
+}
+
+int pbSimSetPhaseDraws(pbSim *S, unsigned draws) {
+  if (!S) return PB_ERR_ARG;
+  S->phaseDraws = draws;
+  return PB_OK;
+}
+
+int pbSimStep(pbSim *S, float deltaTime, float sort_interval, int nsteps, int *steps_done) {
+  if (!S || nsteps < 0) return PB_ERR_ARG;
+  if (steps_done) *steps_done = 0;
+  return stepMany(S, deltaTime, sort_interval, nsteps, steps_done);
+}
+
+int pbSimStepTimed(pbSim *S, float deltaTime, float sort_interval, int nsteps, int *steps_done,
+                   float *elapsed_ms) {
+  if (!S || nsteps < 0) return PB_ERR_ARG;
+  if (steps_done) *steps_done = 0;
+  PB_TRY(hipEventRecord(S->ev0, S->stream));
+  const int rc = stepMany(S, deltaTime, sort_interval, nsteps, steps_done);
+  if (rc) return rc;
+  PB_TRY(hipEventRecord(S->ev1, S->stream));
+  PB_TRY(hipEventSynchronize(S->ev1));
+  float ms = 0.0f;
+  PB_TRY(hipEventElapsedTime(&ms, S->ev0, S->ev1));
+  if (elapsed_ms) *elapsed_ms = ms;
+  return PB_OK;
+}
+
+int pbSimSynchronize(pbSim *S) {
+  if (!S) return PB_ERR_ARG;
+  PB_TRY(hipStreamSynchronize(S->stream));
+  return PB_OK;
+}
+
+int pbSimCentroid(pbSim *S, double *cx, double *cy) {
+  if (!S) return PB_ERR_ARG;
+  const int rc = gatherToStage(S);
+  if (rc) return rc;
+  const uint32_t nb = cdiv(S->n, TILE);
+  hipLaunchKernelGGL(k_com_partial, dim3(nb), dim3(TILE), 0, S->stream, (const float2 *)S->stage, S->n,
+                     S->comPartial);
+  hipLaunchKernelGGL(k_com_final, dim3(1), dim3(64), 0, S->stream, S->comPartial, nb, S->n, S->comOut);
+  PB_TRY(hipGetLastError());
+  PB_TRY(hipMemcpyAsync(S->hCom, S->comOut, sizeof(double2), hipMemcpyDeviceToHost, S->stream));
+  PB_TRY(hipStreamSynchronize(S->stream));
+  if (cx) *cx = S->hCom->x;
+  if (cy) *cy = S->hCom->y;
+  return PB_OK;
+}
+
+int pbSimGetStats(pbSim *S, pbSimStats *stats) {
+  if (!S || !stats) return PB_ERR_ARG;
+  *stats = S->stats;
+  return PB_OK;
+}
+
+int pbSimSetResortEveryStep(pbSim *S, int on) {
+  if (!S) return PB_ERR_ARG;
+  S->resortEveryStep = on != 0;
+  return PB_OK;
+}
+
+}  // extern "C"

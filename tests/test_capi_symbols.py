@@ -1,0 +1,63 @@
+"""CPU test: the C-ABI library loads and exports every symbol include/particlebot_hip.h declares
+(no compute calls: there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "particlebot_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set()
+    for m in re.finditer(r"\b([A-Za-z_]\w*)\s*\(", text):
+        name = m.group(1)
+        if name in {"defined", "sizeof"}:
+            continue
+        names.add(name)
+    return names
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from particlerobotsimulations_amd import _capi
+    if not os.path.exists(_capi.HIP_SO):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _capi
+
+
+def test_header_and_binding_agree(capi):
+    declared = _declared_symbols()
+    assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
+
+
+def test_library_exports_every_symbol(capi):
+    L = capi.lib()
+    for name in capi.SYMBOLS:
+        assert hasattr(L, name), name
+
+
+def test_simparams_layout_matches_reference_struct(capi):
+    """SimParams keeps the reference's field order/types (particlebot_kernel.cuh:58-120):
+    float2/uint2 8-byte aligned as in CUDA/HIP, 8-byte pointers.  The same numbers are
+    static_assert'ed against the C++ struct in csrc/pb_device.hpp."""
+    import ctypes as C
+    P = capi.SimParams
+    assert P.gridSize.offset == 0 and P.numCells.offset == 8 and P.worldOrigin.offset == 16
+    assert P.nCells.offset == 32 and P.nDead.offset == 36 and P.gravity.offset == 44
+    assert P.nobstacles.offset == 144 and P.x1obs.offset == 152 and P.y2obs.offset == 176
+    assert P.n_cir_obstacles.offset == 184 and P.x_cir_obs.offset == 192 and P.Nx.offset == 216
+    assert P.max_time.offset == 248 and C.sizeof(P) == 256
+
+
+def test_engine_rejects_bad_arguments_without_a_gpu(capi):
+    import ctypes as C
+    L = capi.lib()
+    h = C.c_void_p()
+    assert L.pbSimCreate(C.byref(h), None, 0.0) == 2  # PB_ERR_ARG
+    p, keep = capi.make_params({"gridSize": (500, 512), "numCells": 500 * 512, "nCells": 10})
+    assert L.pbSimCreate(C.byref(h), C.byref(p), 0.0) == 2
+    assert b"power of two" in L.pbGetLastErrorString()

@@ -1,0 +1,227 @@
+"""GPU parity of the resident fused engine (pbSim*, include/particlebot_hip.h part 2) against the
+CPU oracle's whole-simulation object and against the reference-probe golden snapshots.
+
+The engine keeps state cell-sorted and fuses step n's forces with step n+1's radius/integration,
+but the arithmetic and summation order are the reference's, so everything here is BIT-EXACT
+(uint32 compare of fp32), far inside the 1e-5 relative tolerance BASELINE.json asks for."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_bit_equal, jittered_blob, max_rel_err, simparams_from_orc
+
+pytestmark = pytest.mark.gpu
+
+STATE_KEYS = ("pos", "vel", "rad", "phase", "absForce_a", "absForce_r")
+
+
+@pytest.fixture(scope="module")
+def pb():
+    import particlerobotsimulations_amd as pb
+    pb.legacy.cudaInit(0, None)
+    return pb
+
+
+def make_pair(pb, orc, P, hex=False, wall_half=0.0):
+    """Oracle sim (placed by the oracle) and an engine sim loaded with the same initial state."""
+    osim = orc.Sim(P, reset=True, hex=hex)
+    sp, keep = simparams_from_orc(P)
+    gsim = pb.Sim(sp, wall_half=wall_half, keepalive=keep)
+    gsim.set_state(pos=osim.get("pos"), vel=osim.get("vel"), rad=osim.get("rad"), phase=osim.get("phase"),
+                   dead=osim.get("dead"))
+    return osim, gsim
+
+
+def compare(osim, gsim, what):
+    st = gsim.get_state()
+    for k in STATE_KEYS:
+        assert_bit_equal(st[k], osim.get(k), f"{what}: {k}")
+    assert gsim.time == osim.time, (what, gsim.time, osim.time)
+
+
+def test_golden_reference_probe(pb, orc, golden_dir):
+    """Engine started from the reference's own initial placement reproduces the reference-probe
+    position snapshots (tests/golden/ref_probe) bit for bit through a phase update (step 1200),
+    and at step 20000, i.e. after the re-sort at step 18000."""
+    P = orc.default_params(nCells=300, nDead=0, seed=5555, light_x=-2.0, light_y=4.0, phase_std=0.0, max_time=1e9)
+    g = lambda k: np.fromfile(os.path.join(golden_dir, "ref_probe", f"example_like_pos_step{k}.bin"),
+                              dtype=np.float32).reshape(-1, 2)
+    sp, keep = simparams_from_orc(P)
+    sim = pb.Sim(sp, keepalive=keep)
+    n = 300
+    sim.set_state(pos=g(0), vel=np.zeros((n, 2), np.float32), rad=np.full(n, P.min_radius, np.float32),
+                  phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
+    step = 0
+    for k in (1, 2, 5, 10, 20, 50, 100, 200, 400, 1000, 5000, 20000):
+        assert sim.step(k - step) == k - step
+        step = k
+        assert_bit_equal(sim.get_state()["pos"], g(k), f"golden step {k}")
+    s = sim.stats()
+    assert s["steps"] == 20000 and s["resorts"] == 2 and s["phase_updates"] == 17
+    assert s["fused_launches"] > 19900  # one kernel per step except at batch ends
+
+
+@pytest.mark.parametrize("case", ["example", "noise", "payload", "circles", "rects", "shadow"])
+def test_whole_sim_vs_oracle(pb, orc, case):
+    """Every state array after 1, 10, 100, 1199, 1200, 1201 and 2500 steps (1200 = phase update)."""
+    kw = dict(nCells=300, nDead=0, seed=5555, light_x=-2.0, light_y=4.0, phase_std=0.0, max_time=1e9)
+    if case == "noise":
+        kw.update(phase_std=0.6)
+    elif case == "payload":
+        kw.update(nCells=201, nDead=-1, seed=9999, light_x=-5.0, light_y=0.0, massFactor=2.0, frictionFactor=1.5,
+                  attractionFactor=0.25)
+    elif case == "circles":
+        kw.update(nCells=500, seed=7777, light_x=-5.0, light_y=0.0, n_cir_obstacles=3, x_cir_obs=[4.2, 2.0, 2.5],
+                  y_cir_obs=[0.3, 2.0, -2.5], r_cir_obs=[0.5, 0.3, 0.45])
+    elif case == "rects":
+        kw.update(nCells=600, seed=8888, light_x=-5.0, light_y=0.0, nobstacles=2, x1obs=[3.9, 3.9],
+                  x2obs=[4.1, 4.1], y1obs=[-8.0, 0.3], y2obs=[-0.3, 8.0])
+    elif case == "shadow":
+        kw.update(nCells=400, seed=4242, light_x=-5.0, light_y=0.0, light_shadow=1, n_cir_obstacles=1,
+                  x_cir_obs=[3.5], y_cir_obs=[0.0], r_cir_obs=[0.6])
+    P = orc.default_params(**kw)
+    osim, gsim = make_pair(pb, orc, P)
+    step = 0
+    for k in (1, 10, 100, 1199, 1200, 1201, 2500):
+        osim.run(k - step)
+        assert gsim.step(k - step) == k - step
+        step = k
+        compare(osim, gsim, f"{case} step {k}")
+
+
+def test_fused_equals_stepwise(pb, orc):
+    """Batched (fused) stepping and one-step-at-a-time (unfused) stepping give identical states."""
+    P = orc.default_params(nCells=1000, nDead=0, seed=31, phase_std=0.6, max_time=1e9)
+    osim, a = make_pair(pb, orc, P)
+    _, b = make_pair(pb, orc, P)
+    a.step(1500)
+    for _ in range(1500):
+        b.step(1)
+    sa, sb = a.get_state(), b.get_state()
+    for k in STATE_KEYS:
+        assert_bit_equal(sa[k], sb[k], k)
+    assert a.stats()["fused_launches"] == 1499 and b.stats()["fused_launches"] == 0
+
+
+def test_dead_bots_and_10k(pb, orc):
+    """BASELINE config 2b: example_dead_cells.cfg scaled to 10^4 bots, 20 % dead (dead set given to
+    both sides; the host-side rand() draw is tested with the Particlebot class)."""
+    P = orc.default_params(nCells=10000, nDead=0, seed=6666, light_x=-2.0, light_y=2.0, phase_std=0.0, max_time=1e9)
+    osim, gsim = make_pair(pb, orc, P)
+    rng = np.random.default_rng(0)
+    dead = np.zeros(P.nCells, np.int32)
+    dead[rng.choice(P.nCells, 2000, replace=False)] = 1
+    osim.set("dead", dead)
+    gsim.set_state(dead=dead)
+    step = 0
+    for k in (1, 10, 300):
+        osim.run(k - step)
+        gsim.step(k - step)
+        step = k
+        compare(osim, gsim, f"10k step {k}")
+
+
+def test_walls_and_grid_wrap(pb, orc):
+    """A blob pushed into the +x/+y corner of the world: wall clamps every step, cells beyond the
+    512 x 0.235 = 120.3 grid span alias through the `& 511` wrap (impl.cuh:117-118), and the 5-cell
+    row of the stencil splits across the x edge of the hash grid."""
+    rng = np.random.default_rng(9)
+    n = 3000
+    P = orc.default_params(nCells=n, nDead=0, seed=9, phase_std=0.0, max_time=1e9, light_x=80.0, light_y=80.0)
+    osim, gsim = make_pair(pb, orc, P)
+    pos, vel, rad = jittered_blob(n, 0.16, rng, center=(58.0, 60.0))
+    pos[: n // 2, 0] += 1.0  # straddle x = 56.3 where cell index 512 wraps to 0
+    vel += np.float32(0.5)
+    for s in (osim,):
+        s.set("pos", pos), s.set("vel", vel), s.set("rad", rad)
+    gsim.set_state(pos=pos, vel=vel, rad=rad)
+    step = 0
+    for k in (1, 5, 50, 400):
+        osim.run(k - step)
+        gsim.step(k - step)
+        step = k
+        compare(osim, gsim, f"walls step {k}")
+    assert (osim.get("pos").max() > 63.8), "blob never reached the wall"
+
+
+def test_generalised_arena_and_resort_schedule(pb, orc):
+    """Extension: 2048^2 grid, walls at +-240 (the 10^6-bot arena of SURVEY 8(d) config 3) on a
+    hex-lattice crop, with sort_interval shortened so several re-sorts happen."""
+    P = orc.default_params(nCells=20000, nDead=0, seed=1, phase_std=0.0, max_time=1e9, light_x=-230.0, light_y=0.0,
+                           grid=2048, arena_half=240.0)
+    osim, gsim = make_pair(pb, orc, P, hex=True, wall_half=240.0)
+    step = 0
+    for k in (1, 20, 130):
+        osim.run(k - step, sort_interval=0.5)
+        gsim.step(k - step, sort_interval=0.5)
+        step = k
+        compare(osim, gsim, f"arena step {k}")
+    # the fp32 schedule gate of particlebot.cpp:256, replayed on the host
+    t, dt, si, expect = np.float32(0), np.float32(0.01), np.float32(0.5), 0
+    for _ in range(130):
+        expect += int(t - si * np.floor(t / si) < dt)
+        t = np.float32(t + dt)
+    assert expect >= 3 and gsim.stats()["resorts"] == expect
+
+
+def test_max_time_stops(pb, orc):
+    """update() past max_time: the reference exits the process (particlebot.cpp:174-176); the
+    engine returns the number of steps it actually ran."""
+    P = orc.default_params(nCells=100, nDead=0, seed=3, phase_std=0.0, max_time=0.055)
+    osim, gsim = make_pair(pb, orc, P)
+    ran = 0
+    while not osim.update():
+        ran += 1
+    assert gsim.step(100) == ran
+    compare(osim, gsim, "after max_time")
+    assert gsim.step(5) == 0
+
+
+def test_resort_every_step_option_differs_only_statistically(pb, orc):
+    """Per-step rebuild is an option, never the default: it changes which neighbours a drifted bot
+    sees, so trajectories differ in the last bits but stay close over a short window."""
+    P = orc.default_params(nCells=2000, nDead=0, seed=77, phase_std=0.0, max_time=1e9)
+    _, a = make_pair(pb, orc, P)
+    _, b = make_pair(pb, orc, P)
+    b.set_resort_every_step(True)
+    a.step(200), b.step(200)
+    assert b.stats()["resorts"] == 200 and a.stats()["resorts"] == 1
+    assert max_rel_err(a.get_state()["pos"], b.get_state()["pos"]) < 1e-2
+
+
+def test_centroid_matches_host(pb, orc):
+    P = orc.default_params(nCells=5000, nDead=0, seed=12, phase_std=0.0, max_time=1e9)
+    osim, gsim = make_pair(pb, orc, P)
+    gsim.step(50)
+    osim.run(50)
+    cx, cy = gsim.centroid()
+    ref = osim.get("pos").astype(np.float64).mean(0)
+    assert abs(cx - ref[0]) < 1e-9 and abs(cy - ref[1]) < 1e-9
+
+
+def test_million_bots_bit_exact_and_properties(pb, orc):
+    """BASELINE.json's headline size: 10^6 bots on the hex lattice in the generalised arena.
+    (1) the first 6 steps are bit-identical to the oracle on the full state;
+    (2) size-independent properties afterwards: radii stay inside [min,max], nobody leaves the
+        arena, the lattice's symmetric centroid stays near the origin, fused == stepwise."""
+    n = 1_000_000
+    P = orc.default_params(nCells=n, nDead=0, seed=1, phase_std=0.0, max_time=1e9, light_x=-230.0, light_y=0.0,
+                           grid=2048, arena_half=240.0)
+    osim, gsim = make_pair(pb, orc, P, hex=True, wall_half=240.0)
+    _, ssim = make_pair(pb, orc, P, hex=True, wall_half=240.0)
+    osim.run(6)
+    gsim.step(6)
+    for _ in range(6):
+        ssim.step(1)
+    compare(osim, gsim, "1e6 bots, 6 steps")
+    sg, ss = gsim.get_state(), ssim.get_state()
+    for k in STATE_KEYS:
+        assert_bit_equal(sg[k], ss[k], f"fused vs stepwise {k}")
+    gsim.step(60)
+    st = gsim.get_state()
+    assert np.isfinite(st["pos"]).all() and np.isfinite(st["vel"]).all()
+    assert st["rad"].min() >= P.min_radius and st["rad"].max() <= P.max_radius
+    assert np.abs(st["pos"]).max() < 240.0
+    cx, cy = gsim.centroid()
+    assert abs(cx) < 0.05 and abs(cy) < 0.05
