@@ -85,7 +85,7 @@ def cpu_baseline(n_bots, budget_s=12.0):
     from oracle import orclib
     P = orclib.default_params(nCells=n_bots, nDead=0, seed=1, phase_std=0.0, max_time=1e9, light_x=-230.0,
                               light_y=0.0, grid=2048, arena_half=240.0)
-    cores = os.cpu_count() or 1
+    cores = orclib.usable_cpus()
     orclib.lib().orc_set_num_threads(cores)
     sim = orclib.Sim(P, reset=True, hex=True)
     sim.run(1)  # first step: includes the initial sort

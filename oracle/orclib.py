@@ -72,6 +72,23 @@ def build(force=False):
     return _SO
 
 
+def usable_cpus():
+    """CPUs this process may really use: scheduler affinity, capped by the cgroup CPU quota.
+    (An OpenMP team larger than that spins at every barrier and runs orders of magnitude slower.)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 _lib = None
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -127,6 +144,7 @@ def lib():
     L.orc_sim_dump.restype = C.c_int
     L.orc_sim_load_from_file.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_sim_load_from_file.restype = C.c_int
+    L.orc_set_num_threads(usable_cpus())
     _lib = L
     return L
 

@@ -17,6 +17,9 @@
 #include <omp.h>
 #endif
 
+/* below this many bots every loop runs on the calling thread (fork/join costs more than the work) */
+#define ORC_OMP_MIN_N 20000u
+
 #define ORC_PI_F 3.141592654f /* particlebot.cpp:21-23 CUDART_PI_F fallback */
 
 /* ------------------------------------------------------------------------------------------ */
@@ -239,7 +242,7 @@ void orc_params_derive(OrcParams *p, uint32_t grid_override, float arena_half) {
 void orc_integrateSystem(const OrcParams *P, float *pos, float *vel, const float *rad, float dt,
                          uint32_t n) {
   const float W = P->wallHalf;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= ORC_OMP_MIN_N)
   for (int64_t i = 0; i < (int64_t)n; i++) {
     float px = pos[2 * i], py = pos[2 * i + 1];
     float vx = vel[2 * i], vy = vel[2 * i + 1];
@@ -283,7 +286,7 @@ static inline uint32_t grid_hash(const OrcParams *P, int gx, int gy) {
 
 /* impl.cuh:446-465 calcHashD */
 void orc_calcHash(const OrcParams *P, uint32_t *hash, uint32_t *index, const float *pos, uint32_t n) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= ORC_OMP_MIN_N)
   for (int64_t i = 0; i < (int64_t)n; i++) {
     int gx, gy;
     grid_pos(P, pos[2 * i], pos[2 * i + 1], &gx, &gy);
@@ -330,7 +333,7 @@ void orc_reorderDataAndFindCellStart(const OrcParams *P, uint32_t *cellStart, ui
                                      uint32_t numCells) {
   (void)P;
   memset(cellStart, 0xff, (size_t)numCells * sizeof(uint32_t));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= ORC_OMP_MIN_N)
   for (int64_t i = 0; i < (int64_t)n; i++) {
     uint32_t h = hash[i];
     if (i == 0 || h != hash[i - 1]) {
@@ -351,7 +354,7 @@ void orc_reorderDataAndFindCellStart(const OrcParams *P, uint32_t *cellStart, ui
 void orc_updateRad_light_wave(const OrcParams *P, const float *absForce_a, const float *absForce_r,
                               float *rad, const float *phase, float time, float dt, const int32_t *dead,
                               uint32_t n) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= ORC_OMP_MIN_N)
   for (int64_t i = 0; i < (int64_t)n; i++) {
     if (dead[i]) continue;
     if (phase[i] > 10000000.0f) continue;
@@ -453,7 +456,7 @@ static int in_shadow(const OrcParams *P, float px, float py) {
 void orc_updatePhase(const OrcParams *P, const float *pos, float *phase, float spacing, float max_d,
                      float min_d, uint32_t n) {
   (void)max_d;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= ORC_OMP_MIN_N)
   for (int64_t i = 0; i < (int64_t)n; i++) {
     const float px = pos[2 * i], py = pos[2 * i + 1];
     int visible = 1;
@@ -567,7 +570,7 @@ void orc_collide(const OrcParams *P, float *newVel, float *absForce_a, float *ab
                  float dt) {
   const int payloadMode = (P->nDead == -1);
   const uint32_t payloadIdx = P->nCells - 1;
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 256) if (n >= ORC_OMP_MIN_N)
   for (int64_t ii = 0; ii < (int64_t)n; ii++) {
     const uint32_t i = (uint32_t)ii;
     const float px = sortedPos[2 * i], py = sortedPos[2 * i + 1];
@@ -771,7 +774,7 @@ float orc_normal(uint32_t seed, uint32_t i, uint32_t k) {
 
 /* replaces impl.cuh:43-51 add_normal_noise_kernel: val[i] += std * N(0,1) */
 void orc_add_normal_noise(uint32_t seed, uint32_t draw, float *val, float std, uint32_t n) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= ORC_OMP_MIN_N)
   for (int64_t i = 0; i < (int64_t)n; i++) {
     float noise = std * orc_normal(seed, (uint32_t)i, draw);
     val[i] += noise;
