@@ -166,6 +166,18 @@ int pbSimGetStats(pbSim *sim, pbSimStats *stats);
  * 1: re-sort every step (never the default: it changes trajectories). */
 int pbSimSetResortEveryStep(pbSim *sim, int on);
 
+/* Force-kernel variant of a simulation: 0 reference-shaped branches, 1 branch-free, 2 branch-free
+ * with the fast exact sqrt/division forms (default; falls back to 1 when the simulation's
+ * constants are outside their proven domain).  All variants give bit-identical results. */
+int pbSimSetForceVariant(pbSim *sim, int variant);
+
+/* On-device check that the fast exact forms equal the compiler's IEEE sqrtf and division: every
+ * float in the sqrt domain, and div_samples sampled (numerator, numerator, denominator) triples
+ * inside the division domain.  Reports how many values were checked and how many differed. */
+int pbSelfTest(unsigned long long div_samples, unsigned long long *sqrt_checked,
+               unsigned long long *sqrt_mismatches, unsigned long long *div_checked,
+               unsigned long long *div_mismatches);
+
 #ifdef __cplusplus
 }
 #endif

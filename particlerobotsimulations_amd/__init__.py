@@ -14,7 +14,15 @@ import numpy as np
 from . import _capi
 from ._capi import SimParams, make_params, pbSimStats  # noqa: F401
 
-__all__ = ["Sim", "DeviceArray", "legacy", "SimParams", "make_params", "library_paths"]
+__all__ = ["Sim", "DeviceArray", "legacy", "SimParams", "make_params", "library_paths", "self_test"]
+
+
+def self_test(div_samples=1 << 32):
+    """pbSelfTest: fast exact sqrt/division forms vs the compiler's IEEE forms, on the GPU."""
+    vals = [C.c_ulonglong() for _ in range(4)]
+    _capi.check(_capi.lib().pbSelfTest(int(div_samples), *[C.byref(v) for v in vals]), "pbSelfTest")
+    keys = ("sqrt_checked", "sqrt_mismatches", "div_checked", "div_mismatches")
+    return {k: int(v.value) for k, v in zip(keys, vals)}
 
 
 def library_paths():
@@ -212,6 +220,9 @@ class Sim:
         s = pbSimStats()
         _capi.check(_capi.lib().pbSimGetStats(self._h, C.byref(s)))
         return {k: int(getattr(s, k)) for k, _ in pbSimStats._fields_}
+
+    def set_force_variant(self, variant):
+        _capi.check(_capi.lib().pbSimSetForceVariant(self._h, int(variant)))
 
     def set_resort_every_step(self, on):
         _capi.check(_capi.lib().pbSimSetResortEveryStep(self._h, 1 if on else 0))

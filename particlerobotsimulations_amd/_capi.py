@@ -113,6 +113,8 @@ SYMBOLS = {
     "pbSimCentroid": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pbSimGetStats": (_I, [_VP, C.POINTER(pbSimStats)]),
     "pbSimSetResortEveryStep": (_I, [_VP, _I]),
+    "pbSimSetForceVariant": (_I, [_VP, _I]),
+    "pbSelfTest": (_I, [C.c_ulonglong] + [C.POINTER(C.c_ulonglong)] * 4),
 }
 
 _lib = None

@@ -83,6 +83,19 @@ static inline void pbFlattenParams(PbDevParams &d, const SimParams &p, float wal
   }
 }
 
+// Per-simulation precondition of the fast exact forms (pbDiv2Fast numerators A*n must be 0 or
+// >= 2^-100 with |n| >= 2^-55, distances must stay below 2^11): every attraction constant a pair
+// can see is 0 or in [2^-40, 2^30], and the arena is at most 512 half-wide.
+static inline bool pbFastMathAllowed(const PbDevParams &d) {
+  auto okA = [](float a) { return a == 0.0f || (a >= 0x1p-40f && a <= 0x1p30f); };
+  bool ok = okA(d.attraction) && d.wallHalf <= 512.0f && d.wallHalf > 0.0f;
+  if (d.nDead == -1) {
+    const float a1 = d.attraction * d.attractionFactor;
+    ok = ok && okA(a1) && okA(a1 * d.attractionFactor);
+  }
+  return ok;
+}
+
 // the layout scripts and reference-built callers rely on (particlebot_kernel.cuh:58-120)
 #include <cstddef>
 // (float2/uint2 are 8-byte aligned in HIP exactly as in CUDA, hence the hole after numCells)
@@ -212,6 +225,146 @@ PB_DEV void pbPair(const PbDevParams &P, float ax, float ay, float avx, float av
     F.fx += tx;
     F.fy += ty;
     F.fa += pbLen(tx, ty);
+  }
+}
+
+// ---- exact fp32 sqrt and division without the general-case scaffolding ------------------------
+// hipcc lowers sqrtf(x) to: scale up if x < 2^-96, v_sqrt_f32 (1 ulp), try the two neighbouring
+// floats with one fma each, scale down, pass zero/inf through: 16 instructions.  It lowers a/d to:
+// v_div_scale x2, v_rcp_f32, one Newton step, quotient + two residual corrections, v_div_fmas,
+// v_div_fixup: 11 instructions.  Inside a KNOWN domain the scaling and fix-up parts are no-ops and
+// the remaining instructions give the same correctly rounded result:
+//   pbSqrtFast(x)      == sqrtf(x)   for x == 0 or 2^-96 <= x <= FLT_MAX (and +inf)
+//   pbDiv2Fast(a,b,d)  == (a/d, b/d) for normal d with |d| <= 2^126, each numerator either +0 or
+//                                    >= 2^-100 in magnitude, and a normal quotient below 2^96
+// The two quotients share the reciprocal and its Newton step.  pbSelfTestFastMath() (C-ABI
+// pbSelfTest) checks both claims on the GPU: every float for sqrt, 2^32 sampled triples for div.
+PB_DEV float pbSqrtFast(float x) {
+  const float y = __builtin_amdgcn_sqrtf(x);
+  const float lo = __uint_as_float(__float_as_uint(y) - 1u);
+  const float hi = __uint_as_float(__float_as_uint(y) + 1u);
+  const float elo = __builtin_fmaf(-lo, y, x);
+  const float ehi = __builtin_fmaf(-hi, y, x);
+  float r = elo <= 0.0f ? lo : y;
+  r = ehi > 0.0f ? hi : r;
+  return r;
+}
+
+PB_DEV void pbDiv2Fast(float a, float b, float d, float &qa, float &qb) {
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  float q = a * r;
+  float t = __builtin_fmaf(-d, q, a);
+  q = __builtin_fmaf(t, r, q);
+  t = __builtin_fmaf(-d, q, a);
+  qa = __builtin_fmaf(t, r, q);
+  q = b * r;
+  t = __builtin_fmaf(-d, q, b);
+  q = __builtin_fmaf(t, r, q);
+  t = __builtin_fmaf(-d, q, b);
+  qb = __builtin_fmaf(t, r, q);
+}
+
+// x is a non-negative float (or NaN): true when it is nonzero but below 2^-96, the only
+// non-negative inputs for which pbSqrtFast may differ from sqrtf
+PB_DEV bool pbTinyNonzero(float x) { return __float_as_uint(x) - 1u < 0x0F800000u - 1u; }
+
+// A lane may use the fast forms for all its pairs when neither of its coordinates is within 2^-20
+// of zero: then every nonzero coordinate difference is >= 2^-44 (it is a multiple of the ulp of a
+// number >= 2^-20), which keeps every numerator in pbDiv2Fast's domain (see DESIGN.md "Fast exact
+// math" for the chain of bounds, including the host-side check on the attraction constants).
+PB_DEV bool pbLaneFastMathOk(float x, float y) { return fabsf(x) >= 0x1p-20f && fabsf(y) >= 0x1p-20f; }
+
+// ---- the same pair force, evaluated without divergent branches --------------------------------
+// In a dense blob every 64-lane wave holds, at every neighbour iteration, some lane in contact,
+// some in the constant-attraction band and most in the 1/gap^2 tail, so the branchy form above
+// executes ALL its paths each iteration.  Here the shared work (distance, unit vector) is hoisted,
+// every regime's coefficient is computed once, and selects pick the result -- the selected value
+// is produced by exactly the operations of the taken branch above, so results are bit-identical.
+//
+// K of the linear band, (A/near2^2 - min)/(near2-near1) (impl.cuh:585-586), only depends on A
+PB_DEV float pbBandSlope(float attraction) {
+  const float near1 = 0.0009f, near2 = 0.0019f, fmin_attr = 2.5f;
+  return (attraction / (near2 * near2) - fmin_attr) / (near2 - near1);
+}
+
+// live: false for the lane's own slot (the reference skips j == index, impl.cuh:638); such a lane
+// computes on garbage (0/0) and accumulates nothing.  velB is only called when some lane of the
+// wave is in contact, and only by those lanes.
+// FAST: use pbSqrtFast / pbDiv2Fast; the caller guarantees their domains (pbLaneFastMathOk for
+// every lane of the wave + the per-simulation check pbFastMathAllowed), except for the force
+// magnitude's square root, whose input is checked here wave-wide and sent to sqrtf if tiny.
+template <bool FAST, class VelFetch>
+PB_DEV void pbPairFlat(const PbDevParams &P, bool live, float ax, float ay, float avx, float avy, float ra,
+                       float bx, float by, float rb, float attraction, float slope, VelFetch velB,
+                       PbForce &F) {
+  const float near1 = 0.0009f, near2 = 0.0019f, fmin_attr = 2.5f;
+  const float rx = bx - ax, ry = by - ay;
+  const float d2 = pbDot(rx, ry, rx, ry);
+  float dist, nx, ny;
+  if (FAST) {
+    dist = pbSqrtFast(d2);  // d2 is 0 or >= 2^-88 here (coordinate differences are 0 or >= 2^-44)
+    pbDiv2Fast(rx, ry, dist, nx, ny);
+  } else {
+    dist = sqrtf(d2);
+    nx = rx / dist;
+    ny = ry / dist;
+  }
+  const float reach = ra + rb;
+  const bool contact = dist < reach;
+  // no contact: constant band, linear band, inverse-square tail
+  const float gap = dist - reach;
+  const float g2 = gap * gap;
+  float farx, fary;
+  if (FAST) {
+    pbDiv2Fast(attraction * nx, attraction * ny, g2, farx, fary);
+  } else {
+    farx = attraction * nx / g2;
+    fary = attraction * ny / g2;
+  }
+  const float band = gap < near1 ? fmin_attr : fmin_attr + slope * (gap - near1);
+  float tx = gap < near2 ? band * nx : farx;
+  float ty = gap < near2 ? band * ny : fary;
+  // contact: spring + dashpot + shear
+  if (__ballot(contact && live) != 0ull) {
+    float2 vb = make_float2(0.0f, 0.0f);
+    if (contact) vb = velB();
+    const float rvx = vb.x - avx, rvy = vb.y - avy;
+    const float vn = pbDot(rvx, rvy, nx, ny);
+    const float tvx = rvx - vn * nx, tvy = rvy - vn * ny;
+    const float ks = -P.spring * (reach - dist);
+    float cx = 0.0f, cy = 0.0f;
+    cx += ks * nx;
+    cy += ks * ny;
+    cx += P.damping * rvx;
+    cy += P.damping * rvy;
+    cx += P.shear * tvx;
+    cy += P.shear * tvy;
+    if (contact) {
+      tx = cx;
+      ty = cy;
+    } else {
+      tx = 0.0f + tx;
+      ty = 0.0f + ty;
+    }
+  } else {
+    tx = 0.0f + tx;  // `tempforce += ...` onto (0,0): turns -0 into +0
+    ty = 0.0f + ty;
+  }
+  const float m2 = pbDot(tx, ty, tx, ty);
+  float mag;
+  if (FAST) {
+    mag = pbSqrtFast(m2);
+    if (__ballot(live && pbTinyNonzero(m2)) != 0ull) mag = sqrtf(m2);
+  } else {
+    mag = sqrtf(m2);
+  }
+  if (live) {
+    F.fx += tx;
+    F.fy += ty;
+    if (contact) F.fr += mag;
+    else F.fa += mag;
   }
 }
 

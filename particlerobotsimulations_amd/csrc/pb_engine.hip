@@ -22,6 +22,7 @@
 //    attractionFactor (impl.cuh:629-633,640-644) rides in .w so the pair loop has no index lookups.
 #include <cstring>
 #include <string>
+#include <type_traits>
 
 #include "particlebot_hip.h"
 #include "pb_device.hpp"
@@ -63,7 +64,11 @@ __global__ __launch_bounds__(TILE) void k_state(PbDevParams P, float4 *__restric
 }
 
 // Forces + kick of step n (impl.cuh:657-831); with FUSE also radius + integration of step n+1.
-template <bool FUSE>
+// PAYLOAD: object-transport mode (nDead == -1), per-pair attraction factors.  FLAT: branch-free
+// pair evaluation (pbPairFlat) instead of the reference-shaped branches (pbPair).
+// FASTOK: the simulation passed pbFastMathAllowed, so waves whose lanes all pass
+// pbLaneFastMathOk may use the exact fast sqrt/division forms.
+template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK>
 __global__ __launch_bounds__(TILE) void k_force(PbDevParams P, const float4 *__restrict__ prIn,
                                                 const float2 *__restrict__ velIn, float4 *__restrict__ prOut,
                                                 float2 *__restrict__ velOut, const float *__restrict__ phase,
@@ -81,9 +86,8 @@ __global__ __launch_bounds__(TILE) void k_force(PbDevParams P, const float4 *__r
   const float4 me = prIn[s];
   float2 v = velIn[s];
   const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
-  const bool payloadMode = (P.nDead == -1);
   bool selfPayload = false;
-  if (payloadMode) selfPayload = (orig[s] == P.nCells - 1u);
+  if (PAYLOAD) selfPayload = (orig[s] == P.nCells - 1u);
   const float att1 = selfPayload ? P.attractionFactor : 1.0f;
 
   PbForce F;
@@ -92,25 +96,38 @@ __global__ __launch_bounds__(TILE) void k_force(PbDevParams P, const float4 *__r
   F.fa = 0.0f;
   F.fr = 0.0f * absR[s];  // impl.cuh:688
 
+  const float slope0 = pbBandSlope(P.attraction);
   const uint32_t GX = P.gridX;
   const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
   const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;  // cells before the x-wrap
   const int nseg = first < 5u ? 2 : 1;
-  for (int dy = -2; dy <= 2; dy++) {
-    const uint32_t row = ((uint32_t)(gy + dy) & (P.gridY - 1u)) * GX;
-    for (int sg = 0; sg < nseg; sg++) {
-      const uint32_t c0 = sg == 0 ? mx0 : 0u;
-      const uint32_t c1 = sg == 0 ? mx0 + first : 5u - first;
-      const uint32_t lo = cellS[row + c0];
-      const uint32_t hi = cellS[row + c1];
-      for (uint32_t j = lo; j < hi; j++) {
-        if (j == s) continue;
-        const float4 q = prIn[j];
-        pbPair(P, me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, P.attraction * q.w * att1,
-               [&]() { return velIn[j]; }, F);
+  auto sweep = [&](auto fastTag) {
+    constexpr bool FAST = decltype(fastTag)::value;
+    for (int dy = -2; dy <= 2; dy++) {
+      const uint32_t row = ((uint32_t)(gy + dy) & (P.gridY - 1u)) * GX;
+      for (int sg = 0; sg < nseg; sg++) {
+        const uint32_t c0 = sg == 0 ? mx0 : 0u;
+        const uint32_t c1 = sg == 0 ? mx0 + first : 5u - first;
+        const uint32_t lo = cellS[row + c0];
+        const uint32_t hi = cellS[row + c1];
+        for (uint32_t j = lo; j < hi; j++) {
+          const float4 q = prIn[j];
+          // payload factors ride in q.w / att1 (impl.cuh:629-633, 640-649)
+          const float A = PAYLOAD ? P.attraction * q.w * att1 : P.attraction;
+          if (FLAT) {
+            const float K = PAYLOAD ? pbBandSlope(A) : slope0;
+            pbPairFlat<FAST>(P, j != s, me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, A, K,
+                             [&]() { return velIn[j]; }, F);
+          } else {
+            if (j != s) pbPair(P, me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, A, [&]() { return velIn[j]; }, F);
+          }
+        }
       }
     }
-  }
+  };
+  // wave-uniform choice: the fast exact forms need every lane's coordinates away from zero
+  if (FLAT && FASTOK && __all(pbLaneFastMathOk(me.x, me.y))) sweep(std::true_type{});
+  else sweep(std::false_type{});
   pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
   pbFrictionAndKick(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
 
@@ -294,6 +311,67 @@ __global__ void k_com_final(const double2 *__restrict__ partial, uint32_t nb, ui
   out[0] = make_double2(sx / (double)n, sy / (double)n);
 }
 
+// ---- self-test of the fast exact math (pbSelfTest) ------------------------------------------
+// every float bit pattern in pbSqrtFast's domain against hipcc's sqrtf
+__global__ __launch_bounds__(256) void k_selftest_sqrt(unsigned long long *__restrict__ mismatches,
+                                                       unsigned long long *__restrict__ checked) {
+  const uint32_t base = (blockIdx.x * 256u + threadIdx.x) * 16u;
+  uint32_t bad = 0, seen = 0;
+  for (uint32_t k = 0; k < 16u; k++) {
+    const uint32_t bits = base + k;
+    const bool inDomain = bits == 0u || (bits >= 0x0F800000u && bits <= 0x7F800000u);
+    if (!inDomain) continue;
+    const float x = __uint_as_float(bits);
+    seen++;
+    if (__float_as_uint(pbSqrtFast(x)) != __float_as_uint(sqrtf(x))) bad++;
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+  if (seen) atomicAdd(checked, (unsigned long long)seen);
+}
+
+// sampled (numerator a, numerator b, denominator d) against hipcc's a/d, b/d, inside
+// v_div_scale_f32's own "no scaling needed" region (which is pbDiv2Fast's domain)
+PB_DEV bool pbDivNoScale(uint32_t nb, uint32_t db) {
+  const int en = (int)((nb >> 23) & 255u), ed = (int)((db >> 23) & 255u);
+  // denominator normal with a normal reciprocal (|d| <= 2^126); numerator >= 2^-100 so that the
+  // residual n - d*q (24+24 bits below n's exponent) is exact -- at 2^-103, where v_div_scale_f32
+  // itself stops scaling, one case in 3e9 rounds the other way; quotient neither near overflow
+  // (exponent gap < 96) nor denormal
+  if ((nb & 0x7FFFFFFFu) == 0u) return (nb == 0u) && ed >= 1 && ed <= 252;  // +0 numerator only
+  return ed >= 1 && ed <= 252 && en >= 27 && en <= 254 && (en - ed) < 96 && (en - ed) > -125;
+}
+
+__global__ __launch_bounds__(256) void k_selftest_div(unsigned long long samplesPerThread, int focused,
+                                                      unsigned long long *__restrict__ mismatches,
+                                                      unsigned long long *__restrict__ checked) {
+  const uint64_t tid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  unsigned long long bad = 0, seen = 0;
+  for (unsigned long long k = 0; k < samplesPerThread; k++) {
+    uint64_t h1 = pbMix64(tid * samplesPerThread + k + (focused ? 0x1234567ull : 0ull));
+    uint64_t h2 = pbMix64(h1 ^ 0x9E3779B97F4A7C15ull);
+    uint32_t ab = (uint32_t)h1, bb = (uint32_t)(h1 >> 32), db = (uint32_t)h2;
+    if (focused) {
+      // the shapes the force kernel produces: |quotient| between 2^-60 and 2^8, d in [2^-50, 2^30]
+      const uint32_t ed = 77u + (uint32_t)((h2 >> 32) % 81u);
+      db = (db & 0x007FFFFFu) | (ed << 23);
+      const uint32_t ea = ed + 8u - (uint32_t)((h2 >> 40) % 69u);
+      const uint32_t eb = ed + 8u - (uint32_t)((h2 >> 48) % 69u);
+      ab = (ab & 0x807FFFFFu) | (ea << 23);
+      bb = (bb & 0x807FFFFFu) | (eb << 23);
+      if (((h2 >> 56) & 15u) == 0u) ab = 0u;  // exact +0 numerators do occur (equal coordinates)
+    }
+    if (!pbDivNoScale(ab, db) || !pbDivNoScale(bb, db)) continue;
+    const float a = __uint_as_float(ab), b = __uint_as_float(bb), d = __uint_as_float(db);
+    float qa, qb;
+    pbDiv2Fast(a, b, d, qa, qb);
+    seen += 2;
+    if (__float_as_uint(qa) != __float_as_uint(a / d)) bad++;
+    if (__float_as_uint(qb) != __float_as_uint(b / d)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+  if (seen) atomicAdd(checked, seen);
+}
+
 }  // namespace
 
 // ---- the object -----------------------------------------------------------------------------
@@ -326,6 +404,7 @@ struct pbSim {
   uint32_t phaseDraws = 0;
   bool haveCells = false;
   bool resortEveryStep = false;
+  int variant = 2;  // force kernel: 0 reference-shaped branches, 1 branch-free, 2 (default) + fast exact math
   pbSimStats stats{};
 };
 
@@ -334,6 +413,35 @@ namespace {
 inline bool gate(float t, float interval, float dt) {
   // the reference's fp32 schedule test (particlebot.cpp:207,212,256)
   return t - interval * floorf(t / interval) < dt;
+}
+
+template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK>
+void launchForceT(pbSim *S, dim3 grid, int c, int o, float dt, float tNext, int doRadiusNext) {
+  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK>), grid, dim3(TILE), 0, S->stream, S->P, S->pr[c], S->vel[c],
+                     S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c], S->cellS,
+                     S->n, dt, tNext, doRadiusNext);
+}
+
+void launchForce(pbSim *S, bool fuse, dim3 grid, int c, int o, float dt, float tNext, int doRadiusNext) {
+  const bool payload = (S->P.nDead == -1);
+  // variant 0: reference-shaped branches; 1: branch-free; 2 (default): branch-free + fast exact math
+  const int kind = S->variant == 0 ? 0 : (S->variant == 1 || !pbFastMathAllowed(S->P)) ? 1 : 2;
+#define PB_CASE(F, PL, K, FL, FA) \
+  if (fuse == F && payload == PL && kind == K) \
+    return launchForceT<F, PL, FL, FA>(S, grid, c, o, dt, tNext, doRadiusNext);
+  PB_CASE(true, true, 0, false, false)
+  PB_CASE(true, true, 1, true, false)
+  PB_CASE(true, true, 2, true, true)
+  PB_CASE(true, false, 0, false, false)
+  PB_CASE(true, false, 1, true, false)
+  PB_CASE(true, false, 2, true, true)
+  PB_CASE(false, true, 0, false, false)
+  PB_CASE(false, true, 1, true, false)
+  PB_CASE(false, true, 2, true, true)
+  PB_CASE(false, false, 0, false, false)
+  PB_CASE(false, false, 1, true, false)
+  PB_CASE(false, false, 2, true, true)
+#undef PB_CASE
 }
 
 int resort(pbSim *S) {
@@ -415,16 +523,9 @@ int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
       if (rc) return rc;
     }
     const int c = S->cur, o = c ^ 1;
-    if (fuse) {
-      hipLaunchKernelGGL(k_force<true>, gF, b, 0, S->stream, S->P, S->pr[c], S->vel[c], S->pr[o], S->vel[o],
-                         S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c], S->cellS, n, dt, tNext,
-                         (int)(lightWave && tNext >= 0));
-      S->stats.fused_launches++;
-    } else {
-      hipLaunchKernelGGL(k_force<false>, gF, b, 0, S->stream, S->P, S->pr[c], S->vel[c], S->pr[o], S->vel[o],
-                         S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c], S->cellS, n, dt, tNext, 0);
-      S->stats.plain_launches++;
-    }
+    launchForce(S, fuse, gF, c, o, dt, tNext, (int)(fuse && lightWave && tNext >= 0));
+    if (fuse) S->stats.fused_launches++;
+    else S->stats.plain_launches++;
     // pr/vel moved to the other copy; the remaining arrays did not.  Swap just those two.
     {
       float4 *tp = S->pr[c];
@@ -504,6 +605,7 @@ int pbSimCreate(pbSim **out, const SimParams *params, float wallHalf) {
   S->host.x_cir_obs = S->host.y_cir_obs = S->host.r_cir_obs = nullptr;
   pbFlattenParams(S->P, *params, wallHalf);
   S->n = params->nCells;
+  if (const char *v = getenv("PB_FORCE_VARIANT")) S->variant = atoi(v);  // A/B switch for benchmarking
   const size_t n = S->n;
 #define PB_TRY_NEW(expr)            \
   do {                              \
@@ -677,6 +779,36 @@ int pbSimCentroid(pbSim *S, double *cx, double *cy) {
 int pbSimGetStats(pbSim *S, pbSimStats *stats) {
   if (!S || !stats) return PB_ERR_ARG;
   *stats = S->stats;
+  return PB_OK;
+}
+
+int pbSimSetForceVariant(pbSim *S, int variant) {
+  if (!S || variant < 0 || variant > 2) return PB_ERR_ARG;
+  S->variant = variant;
+  return PB_OK;
+}
+
+int pbSelfTest(unsigned long long div_samples, unsigned long long *sqrt_checked,
+               unsigned long long *sqrt_mismatches, unsigned long long *div_checked,
+               unsigned long long *div_mismatches) {
+  unsigned long long *d = nullptr;
+  PB_TRY(hipMalloc((void **)&d, 4 * sizeof(unsigned long long)));
+  PB_TRY(hipMemset(d, 0, 4 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_selftest_sqrt, dim3(1u << 20), dim3(256), 0, 0, d + 1, d + 0);
+  const unsigned threads = 4096u * 256u;
+  const unsigned long long per = (div_samples / 2 + threads - 1) / threads;
+  if (per) {
+    hipLaunchKernelGGL(k_selftest_div, dim3(4096), dim3(256), 0, 0, per, 0, d + 3, d + 2);
+    hipLaunchKernelGGL(k_selftest_div, dim3(4096), dim3(256), 0, 0, per, 1, d + 3, d + 2);
+  }
+  PB_TRY(hipGetLastError());
+  unsigned long long h[4];
+  PB_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  PB_TRY(hipFree(d));
+  if (sqrt_checked) *sqrt_checked = h[0];
+  if (sqrt_mismatches) *sqrt_mismatches = h[1];
+  if (div_checked) *div_checked = h[2];
+  if (div_mismatches) *div_mismatches = h[3];
   return PB_OK;
 }
 

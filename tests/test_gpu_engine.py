@@ -227,3 +227,59 @@ def test_million_bots_bit_exact_and_properties(pb, orc):
     assert np.abs(st["pos"]).max() < 240.0
     cx, cy = gsim.centroid()
     assert abs(cx) < 0.05 and abs(cy) < 0.05
+
+
+def test_fast_math_self_test(pb):
+    """pbSelfTest: the fast exact sqrt equals hipcc's IEEE sqrtf on EVERY float of its domain, and
+    the shared-reciprocal division equals IEEE division on 2^31 sampled triples of its domain."""
+    r = pb.self_test(1 << 31)
+    assert r["sqrt_checked"] == (0x7F800000 - 0x0F800000 + 1) + 1, r
+    assert r["sqrt_mismatches"] == 0, r
+    assert r["div_checked"] > (1 << 29), r
+    assert r["div_mismatches"] == 0, r
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_force_kernel_variants_match_oracle(pb, orc, variant):
+    """Reference-shaped, branch-free and fast-exact-math force kernels all match the oracle bit for
+    bit on a state built to sit on the edges of the fast path's domain: bots exactly on the axes,
+    bots with denormal-small / 1e-30 coordinates (fast path must step aside), -0.0 coordinates,
+    1-ulp-apart neighbours, and payload factors."""
+    rng = np.random.default_rng(123)
+    n = 6000
+    P = orc.default_params(nCells=n, nDead=-1, seed=5, phase_std=0.0, max_time=1e9, light_x=-5.0, light_y=0.0,
+                           attractionFactor=0.5, massFactor=2.0)
+    osim, gsim = make_pair(pb, orc, P)
+    gsim.set_force_variant(variant)
+    pos, vel, rad = jittered_blob(n, 0.158, rng, center=(0.0, 0.0), jitter=0.1)
+    k = n // 2
+    pos[k:k + 40, 0] = 0.0           # exactly on the y axis
+    pos[k + 40:k + 80, 1] = 0.0      # exactly on the x axis
+    pos[k + 80:k + 90, 0] = 1e-30    # tiny nonzero coordinates
+    pos[k + 90:k + 100, 1] = -1e-38
+    pos[k + 100:k + 110, 0] = -0.0
+    pos[k + 110] = pos[k + 111]      # coincident pair (0/0 -> NaN in the reference too)
+    vel[k + 110] = vel[k + 111]
+    pos[k + 112] = pos[k + 113] + np.array([np.spacing(pos[k + 113, 0]), 0], np.float32)  # 1 ulp apart
+    for s in (osim,):
+        s.set("pos", pos), s.set("vel", vel), s.set("rad", rad)
+    gsim.set_state(pos=pos, vel=vel, rad=rad)
+    osim.run(3)
+    gsim.step(3)
+    st = gsim.get_state()
+    for key in STATE_KEYS:
+        a, b = st[key], osim.get(key)
+        both_nan = np.isnan(a) & np.isnan(b)  # NaN payloads are not compared
+        assert_bit_equal(np.where(both_nan, 0, a).astype(a.dtype), np.where(both_nan, 0, b).astype(b.dtype),
+                         f"variant {variant}: {key}")
+    assert np.isnan(osim.get("vel")).any(), "the coincident pair was supposed to produce NaN"
+
+
+def test_fast_math_disabled_for_out_of_domain_constants(pb, orc):
+    """An attraction constant below 2^-48 is outside the fast division's proven domain: the engine
+    must fall back (still bit-exact)."""
+    P = orc.default_params(nCells=3000, nDead=0, seed=8, phase_std=0.0, max_time=1e9, attraction=1e-20)
+    osim, gsim = make_pair(pb, orc, P)
+    osim.run(30)
+    gsim.step(30)
+    compare(osim, gsim, "tiny attraction")

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of force-kernel variants in ONE process on ONE device (the methodology of
+cdna_hip_programming.md rule 24): every variant gets its own simulation started from the same
+state; rounds of K steps alternate between them; device time comes from HIP events on each
+simulation's stream.  Also checks that all variants end bit-identical.
+
+  python tools/ab_bench.py --variants 0,1 --bots 1000000 --rounds 6 --steps 200 --skip 100
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", default="0,1")
+    ap.add_argument("--bots", type=int, default=1_000_000)
+    ap.add_argument("--rounds", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--skip", type=int, default=100, help="untimed steps before the first round")
+    ap.add_argument("--spacing", type=float, default=bench.RELAXED_SPACING)
+    args = ap.parse_args()
+    import particlerobotsimulations_amd as pb
+    pb.legacy.cudaInit(0, None)
+    n = args.bots
+    variants = [int(v) for v in args.variants.split(",")]
+    pos = bench.hex_lattice(n, np.float32(args.spacing))
+    sims = {}
+    for v in variants:
+        os.environ["PB_FORCE_VARIANT"] = str(v)
+        sp, keep = bench.workload_params(n, seed=1)
+        s = pb.Sim(sp, wall_half=240.0, keepalive=keep)
+        s.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
+                    phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
+        s.step(args.skip)
+        sims[v] = s
+    times = {v: [] for v in variants}
+    for r in range(args.rounds):
+        for v in variants:
+            done, ms = sims[v].step_timed(args.steps)
+            times[v].append(ms / args.steps * 1e3)
+    ref = sims[variants[0]].get_state()
+    for v in variants:
+        st = sims[v].get_state()
+        same = all(np.array_equal(st[k].view(np.uint32), ref[k].view(np.uint32))
+                   for k in ("pos", "vel", "rad", "absForce_a", "absForce_r"))
+        t = np.array(times[v])
+        print(f"variant {v}: us/step per round {np.round(t, 1).tolist()}  median {np.median(t):.1f}  min {t.min():.1f}  "
+              f"=> {n / np.median(t) * 1e6:.3e} particle-steps/s   bit-identical to variant {variants[0]}: {same}")
+
+
+if __name__ == "__main__":
+    main()

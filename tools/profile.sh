@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + three separate PMC passes of the
+# bench workload, raw output under gpurun_out/prof_<tag>/, then a distilled summary next to it.
+# usage: tools/profile.sh <tag> [bench args...]
+set -u
+TAG=${1:-run}; shift || true
+ARGS=${@:---steps 200 --warmup 20 --no-cpu-baseline}
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+run() { # name, rocprof flags...
+  local name=$1; shift
+  timeout 600 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o "$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1
+  echo "$name rc=$?" >> "$OUT/status.txt"
+}
+run trace --kernel-trace --stats
+run pmc_sq --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+run pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
+run pmc_fetch --pmc FETCH_SIZE
+run pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
+cat "$OUT/summary.md"

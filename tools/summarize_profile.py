@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Distil the rocprofv3 CSVs written by tools/profile.sh into a short markdown summary
+(per-kernel time from the kernel trace; per-kernel PMC averages; HBM traffic corrected as
+MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled for wide coalesced reads, both in KiB)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, pattern):
+    return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+
+
+def short(name):
+    for pre in ("void ", "(anonymous namespace)::"):
+        name = name.replace(pre, "")
+    name = name.split("(")[0]
+    return name.strip()[:60]
+
+
+def kernel_trace(root):
+    rows = []
+    for f in find(os.path.join(root, "trace"), "*kernel_trace.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                rows.append(r)
+    agg = defaultdict(list)
+    meta = {}
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        agg[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        meta[k] = (r.get("VGPR_Count", "?"), r.get("SGPR_Count", "?"), r.get("LDS_Block_Size", "?"),
+                   r.get("Grid_Size", r.get("Grid_Size_X", "?")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", "?")))
+    return agg, meta
+
+
+def pmc(root, sub):
+    out = defaultdict(lambda: defaultdict(list))
+    for f in find(os.path.join(root, sub), "*counter_collection.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    root = sys.argv[1]
+    agg, meta = kernel_trace(root)
+    total = sum(sum(v) for v in agg.values()) or 1
+    print(f"# rocprofv3 summary: {os.path.basename(root)}\n")
+    print("## kernel trace (`rocprofv3 --kernel-trace --stats`)\n")
+    print("| kernel | calls | total ms | avg us | min us | max us | % | VGPR | SGPR | LDS | grid | wg |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        m = meta[k]
+        print(f"| {k} | {len(v)} | {sum(v)/1e6:.3f} | {sum(v)/len(v)/1e3:.2f} | {min(v)/1e3:.2f} | {max(v)/1e3:.2f} | "
+              f"{100*sum(v)/total:.1f} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} |")
+    counters = defaultdict(dict)
+    for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+        for k, cs in pmc(root, sub).items():
+            for c, vals in cs.items():
+                counters[k][c] = sum(vals) / len(vals)
+    print("\n## PMC averages per launch (separate passes)\n")
+    for k, cs in sorted(counters.items(), key=lambda kv: -sum(agg.get(kv[0], [0]))):
+        if k not in agg or sum(agg[k]) / total < 0.01:
+            continue
+        print(f"### {k}\n")
+        for c, v in sorted(cs.items()):
+            print(f"- {c}: {v:.4g}")
+        d = cs
+        avg_ns = sum(agg[k]) / len(agg[k])
+        if "SQ_ACTIVE_INST_VALU" in d and "SQ_BUSY_CYCLES" in d:
+            # SQ_* cycle counters are summed over SEs/XCDs; report ratios only
+            if d.get("SQ_WAVE_CYCLES"):
+                print(f"- derived: VALU issue share of wave cycles = {4*d['SQ_ACTIVE_INST_VALU']/d['SQ_WAVE_CYCLES']:.3f} "
+                      f"(ACTIVE_INST_VALU x4 / WAVE_CYCLES, both quad-cycle units)")
+            if d.get("SQ_INSTS_VALU") and d.get("SQ_WAVES"):
+                print(f"- derived: VALU instructions per wave = {d['SQ_INSTS_VALU']/d['SQ_WAVES']:.1f}")
+            if d.get("SQ_THREAD_CYCLES_VALU") and d.get("SQ_ACTIVE_INST_VALU"):
+                print(f"- derived: VALU lane utilisation = "
+                      f"{d['SQ_THREAD_CYCLES_VALU']/d['SQ_ACTIVE_INST_VALU']/64:.3f} "
+                      f"(THREAD_CYCLES_VALU / (ACTIVE_INST_VALU x 64))")
+        if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+            fetch = 2.0 * d.get("FETCH_SIZE", 0.0) * 1024  # gfx950: reports half of wide coalesced reads
+            write = d.get("WRITE_SIZE", 0.0) * 1024
+            print(f"- derived: HBM-side traffic per launch = read {fetch/1e6:.1f} MB (FETCH_SIZE x2 x1024) + "
+                  f"write {write/1e6:.1f} MB = {(fetch+write)/1e6:.1f} MB; at {avg_ns/1e3:.1f} us/launch = "
+                  f"{(fetch+write)/avg_ns:.1f} GB/s")
+        if d.get("TCC_HIT_sum") is not None and d.get("TCC_MISS_sum") is not None:
+            h, m = d["TCC_HIT_sum"], d["TCC_MISS_sum"]
+            if h + m:
+                print(f"- derived: L2 hit rate = {h/(h+m):.3f}")
+        print()
+
+
+if __name__ == "__main__":
+    main()
