@@ -295,10 +295,17 @@ PB_DEV float pbBandSlope(float attraction) {
 // FAST: use pbSqrtFast / pbDiv2Fast; the caller guarantees their domains (pbLaneFastMathOk for
 // every lane of the wave + the per-simulation check pbFastMathAllowed), except for the force
 // magnitude's square root, whose input is checked here wave-wide and sent to sqrtf if tiny.
+//
+// Split in two so that a loop can evaluate several neighbours' forces as independent instruction
+// streams (the evaluation is one long dependent chain) and then add them in the reference's order.
+struct PbPairTerm {
+  float tx, ty, mag;
+  bool contact;
+};
+
 template <bool FAST, class VelFetch>
-PB_DEV void pbPairFlat(const PbDevParams &P, bool live, float ax, float ay, float avx, float avy, float ra,
-                       float bx, float by, float rb, float attraction, float slope, VelFetch velB,
-                       PbForce &F) {
+PB_DEV PbPairTerm pbPairEval(const PbDevParams &P, bool live, float ax, float ay, float avx, float avy, float ra,
+                             float bx, float by, float rb, float attraction, float slope, VelFetch velB) {
   const float near1 = 0.0009f, near2 = 0.0019f, fmin_attr = 2.5f;
   const float rx = bx - ax, ry = by - ay;
   const float d2 = pbDot(rx, ry, rx, ry);
@@ -327,7 +334,7 @@ PB_DEV void pbPairFlat(const PbDevParams &P, bool live, float ax, float ay, floa
   float tx = gap < near2 ? band * nx : farx;
   float ty = gap < near2 ? band * ny : fary;
   // contact: spring + dashpot + shear
-  if (__ballot(contact && live) != 0ull) {
+  if (__builtin_amdgcn_ballot_w64(contact && live) != 0ull) {
     float2 vb = make_float2(0.0f, 0.0f);
     if (contact) vb = velB();
     const float rvx = vb.x - avx, rvy = vb.y - avy;
@@ -356,16 +363,130 @@ PB_DEV void pbPairFlat(const PbDevParams &P, bool live, float ax, float ay, floa
   float mag;
   if (FAST) {
     mag = pbSqrtFast(m2);
-    if (__ballot(live && pbTinyNonzero(m2)) != 0ull) mag = sqrtf(m2);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(live && pbTinyNonzero(m2)) != 0ull, 0)) {
+      // a real branch, not a select: the empty asm keeps hipcc from computing both roots every time
+      asm volatile("; rare: force magnitude below 2^-48, full sqrtf" ::: "memory");
+      mag = sqrtf(m2);
+    }
   } else {
     mag = sqrtf(m2);
   }
-  if (live) {
-    F.fx += tx;
-    F.fy += ty;
-    if (contact) F.fr += mag;
-    else F.fa += mag;
+  PbPairTerm r;
+  r.tx = tx;
+  r.ty = ty;
+  r.mag = mag;
+  r.contact = contact;
+  return r;
+}
+
+// K neighbours evaluated side by side in the same basic blocks (one shared contact branch, one
+// shared rare-sqrt branch), so the scheduler can interleave K independent dependency chains.
+// Each term equals pbPairEval's for that neighbour.
+template <bool FAST, int K, class VelFetch>
+PB_DEV void pbPairEvalK(const PbDevParams &P, const bool (&live)[K], float ax, float ay, float avx, float avy,
+                        float ra, const float (&bx)[K], const float (&by)[K], const float (&rb)[K],
+                        const float (&attraction)[K], const float (&slope)[K], VelFetch velB,
+                        PbPairTerm (&out)[K]) {
+  const float near1 = 0.0009f, near2 = 0.0019f, fmin_attr = 2.5f;
+  float nx[K], ny[K], dist[K], reach[K], tx[K], ty[K];
+  bool contact[K];
+  bool anyContact = false;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const float rx = bx[k] - ax, ry = by[k] - ay;
+    const float d2 = pbDot(rx, ry, rx, ry);
+    if (FAST) {
+      dist[k] = pbSqrtFast(d2);
+      pbDiv2Fast(rx, ry, dist[k], nx[k], ny[k]);
+    } else {
+      dist[k] = sqrtf(d2);
+      nx[k] = rx / dist[k];
+      ny[k] = ry / dist[k];
+    }
+    reach[k] = ra + rb[k];
+    contact[k] = dist[k] < reach[k];
+    const float gap = dist[k] - reach[k];
+    const float g2 = gap * gap;
+    float farx, fary;
+    if (FAST) {
+      pbDiv2Fast(attraction[k] * nx[k], attraction[k] * ny[k], g2, farx, fary);
+    } else {
+      farx = attraction[k] * nx[k] / g2;
+      fary = attraction[k] * ny[k] / g2;
+    }
+    const float band = gap < near1 ? fmin_attr : fmin_attr + slope[k] * (gap - near1);
+    tx[k] = gap < near2 ? band * nx[k] : farx;
+    ty[k] = gap < near2 ? band * ny[k] : fary;
+    anyContact = anyContact || (contact[k] && live[k]);
   }
+  if (__builtin_amdgcn_ballot_w64(anyContact) != 0ull) {
+    float2 vb[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      vb[k] = make_float2(0.0f, 0.0f);
+      if (contact[k]) vb[k] = velB(k);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const float rvx = vb[k].x - avx, rvy = vb[k].y - avy;
+      const float vn = pbDot(rvx, rvy, nx[k], ny[k]);
+      const float tvx = rvx - vn * nx[k], tvy = rvy - vn * ny[k];
+      const float ks = -P.spring * (reach[k] - dist[k]);
+      float cx = 0.0f, cy = 0.0f;
+      cx += ks * nx[k];
+      cy += ks * ny[k];
+      cx += P.damping * rvx;
+      cy += P.damping * rvy;
+      cx += P.shear * tvx;
+      cy += P.shear * tvy;
+      tx[k] = contact[k] ? cx : 0.0f + tx[k];
+      ty[k] = contact[k] ? cy : 0.0f + ty[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      tx[k] = 0.0f + tx[k];  // `tempforce += ...` onto (0,0): turns -0 into +0
+      ty[k] = 0.0f + ty[k];
+    }
+  }
+  float m2[K];
+  bool anyTiny = false;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    m2[k] = pbDot(tx[k], ty[k], tx[k], ty[k]);
+    out[k].tx = tx[k];
+    out[k].ty = ty[k];
+    out[k].contact = contact[k];
+    if (FAST) {
+      out[k].mag = pbSqrtFast(m2[k]);
+      anyTiny = anyTiny || (live[k] && pbTinyNonzero(m2[k]));
+    } else {
+      out[k].mag = sqrtf(m2[k]);
+    }
+  }
+  if (FAST) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(anyTiny) != 0ull, 0)) {
+      asm volatile("; rare: a force magnitude below 2^-48, full sqrtf" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < K; k++) out[k].mag = sqrtf(m2[k]);
+    }
+  }
+}
+
+PB_DEV void pbPairAdd(bool live, const PbPairTerm &t, PbForce &F) {
+  if (live) {
+    F.fx += t.tx;
+    F.fy += t.ty;
+    if (t.contact) F.fr += t.mag;
+    else F.fa += t.mag;
+  }
+}
+
+template <bool FAST, class VelFetch>
+PB_DEV void pbPairFlat(const PbDevParams &P, bool live, float ax, float ay, float avx, float avy, float ra,
+                       float bx, float by, float rb, float attraction, float slope, VelFetch velB,
+                       PbForce &F) {
+  pbPairAdd(live, pbPairEval<FAST>(P, live, ax, ay, avx, avy, ra, bx, by, rb, attraction, slope, velB), F);
 }
 
 // common tail of obstacle contacts (impl.cuh:711-726 and :781-797): spring term (sx,sy) along the

@@ -43,6 +43,10 @@ thread_local std::string g_lastError;
   } while (0)
 
 constexpr int TILE = 256;
+#ifndef PB_NB
+#define PB_NB 1
+#endif
+constexpr int NB = PB_NB;  // neighbours evaluated side by side per loop trip
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
@@ -110,15 +114,41 @@ __global__ __launch_bounds__(TILE) void k_force(PbDevParams P, const float4 *__r
         const uint32_t c1 = sg == 0 ? mx0 + first : 5u - first;
         const uint32_t lo = cellS[row + c0];
         const uint32_t hi = cellS[row + c1];
-        for (uint32_t j = lo; j < hi; j++) {
-          const float4 q = prIn[j];
-          // payload factors ride in q.w / att1 (impl.cuh:629-633, 640-649)
-          const float A = PAYLOAD ? P.attraction * q.w * att1 : P.attraction;
-          if (FLAT) {
-            const float K = PAYLOAD ? pbBandSlope(A) : slope0;
-            pbPairFlat<FAST>(P, j != s, me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, A, K,
-                             [&]() { return velIn[j]; }, F);
-          } else {
+        if (FLAT) {
+          // NB neighbours per trip, evaluated side by side (independent dependency chains for the
+          // scheduler to interleave) and then summed in slot order.  The next trip's posrad loads
+          // are already in flight (software pipeline).  Out-of-range slots alias the lane's own
+          // slot s, which is never accumulated.
+          float4 q[NB];
+#pragma unroll
+          for (int k = 0; k < NB; k++) q[k] = prIn[lo + k < hi ? lo + k : s];
+          for (uint32_t j = lo; j < hi; j += NB) {
+            bool live[NB];
+            uint32_t idx[NB];
+            float bx[NB], by[NB], rb[NB], A[NB], K[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+              idx[k] = j + k < hi ? j + k : s;
+              live[k] = idx[k] != s;
+              bx[k] = q[k].x;
+              by[k] = q[k].y;
+              rb[k] = q[k].z;
+              // payload factors ride in q.w / att1 (impl.cuh:629-633, 640-649)
+              A[k] = PAYLOAD ? P.attraction * q[k].w * att1 : P.attraction;
+              K[k] = PAYLOAD ? pbBandSlope(A[k]) : slope0;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; k++) q[k] = prIn[j + NB + k < hi ? j + NB + k : s];
+            PbPairTerm t[NB];
+            pbPairEvalK<FAST, NB>(P, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
+                                  [&](int k) { return velIn[idx[k]]; }, t);
+#pragma unroll
+            for (int k = 0; k < NB; k++) pbPairAdd(live[k], t[k], F);
+          }
+        } else {
+          for (uint32_t j = lo; j < hi; j++) {
+            const float4 q = prIn[j];
+            const float A = PAYLOAD ? P.attraction * q.w * att1 : P.attraction;
             if (j != s) pbPair(P, me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, A, [&]() { return velIn[j]; }, F);
           }
         }
