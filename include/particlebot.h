@@ -21,6 +21,23 @@
 #include "particlebot_hip.h"
 #include "particlebot_kernel.h"
 
+/* glibc's rand()/srand() (the TYPE_3 additive-feedback generator of random_r) as an object.  The
+ * reference draws the placement and the dead-bot set from the process-global libc stream seeded
+ * by srand(params.seed) in main (main.cpp:929).  A private stream with the same arithmetic gives
+ * the same numbers, is not disturbed by other users of rand() in the process (the HIP runtime
+ * draws from it while initialising) and lets many simulations live in one process. */
+class PbLibcRand {
+ public:
+  explicit PbLibcRand(unsigned seed = 1) { reseed(seed); }
+  void reseed(unsigned seed);
+  int next(); /* == rand(): 31 bits */
+  static constexpr int kMax = 2147483647; /* RAND_MAX */
+
+ private:
+  int r[34];
+  int f, b; /* front / rear indices into r[3..33] */
+};
+
 class Particlebot {
  public:
   enum class Engine { Fused, Legacy };
@@ -75,6 +92,8 @@ class Particlebot {
   int *getDeadArray();
   /* quiet the reference's per-bot "Placing %d th disc" chatter (particlebot.cpp:645) */
   static void setVerbosePlacement(bool on);
+  /* lattice pitch used by CONFIG_HEX placement; <= 0 selects the reference's 2*min_radius */
+  void setHexSpacing(float pitch) { hexSpacing = pitch; }
   pbSim *engineHandle() { return sim; }
 
  protected:
@@ -114,6 +133,8 @@ class Particlebot {
   Engine engineKind = Engine::Fused;
   float wallHalf = 64.0f;
   bool exitOnMaxTime = true;
+  float hexSpacing = 0.0f;
+  PbLibcRand rng; /* seeded with params.seed at construction */
 };
 
 #endif /* PARTICLEBOT_H */

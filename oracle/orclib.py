@@ -130,6 +130,7 @@ def lib():
     L.orc_sim_reset.argtypes = [C.c_void_p, C.c_int]
     L.orc_sim_update.argtypes = [C.c_void_p, C.c_float, C.c_float]
     L.orc_sim_update.restype = C.c_int
+    L.orc_sim_force_sort_once.argtypes = [C.c_void_p]
     L.orc_sim_time.argtypes = [C.c_void_p]
     L.orc_sim_time.restype = C.c_float
     L.orc_sim_set_time.argtypes = [C.c_void_p, C.c_float]
@@ -231,6 +232,9 @@ class Sim:
     @time.setter
     def time(self, t):
         lib().orc_sim_set_time(self._h, float(t))
+
+    def force_sort_once(self):
+        lib().orc_sim_force_sort_once(self._h)
 
     def update(self, dt=None, sort_interval=None):
         dt = self.P.timestep if dt is None else dt

@@ -131,6 +131,8 @@ int orc_sim_update(OrcSim *s, float dt, float sort_interval);
 int orc_sim_dump(OrcSim *s, FILE *fp, float dump_interval, uint32_t testing, int echo);
 /* particlebot.cpp:369-411 */
 int orc_sim_load_from_file(OrcSim *s, FILE *fp);
+/* test helper, NOT reference behaviour: force the re-hash + sort on the next update */
+void orc_sim_force_sort_once(OrcSim *s);
 float orc_sim_time(const OrcSim *s);
 void orc_sim_set_time(OrcSim *s, float t);
 uint32_t orc_sim_phase_draws(const OrcSim *s);

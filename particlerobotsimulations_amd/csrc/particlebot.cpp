@@ -19,7 +19,8 @@ namespace {
 bool g_verbosePlacement = false;
 constexpr float kPi = 3.141592654f;  // particlebot.cpp:21-23
 
-inline float frand() { return rand() / (float)RAND_MAX; }  // particlebot.cpp:27-30
+// particlebot.cpp:27-30 frand(): rand() / (float)RAND_MAX
+inline float frand(PbLibcRand &g) { return g.next() / (float)PbLibcRand::kMax; }
 // particlebot.cpp:32-34: the host-side length() is powf-based, unlike the device one
 inline float hostLength(float x, float y) { return powf(powf(x, 2.0f) + powf(y, 2.0f), 0.5f); }
 
@@ -63,11 +64,39 @@ struct PlacementGrid {
 
 }  // namespace
 
+// glibc stdlib/random_r.c, TYPE_3 (x^31 + x^3 + 1): srandom_r fills r[0..30] with the Lehmer
+// sequence 16807*x mod (2^31-1), then discards 310 outputs; random_r returns (r[f] += r[b]) >> 1.
+void PbLibcRand::reseed(unsigned seed) {
+  if (seed == 0) seed = 1;
+  int *state = r + 3;
+  state[0] = (int)seed;
+  long word = (int)seed;
+  for (int i = 1; i < 31; i++) {
+    const long hi = word / 127773, lo = word % 127773;
+    word = 16807 * lo - 2836 * hi;
+    if (word < 0) word += 2147483647;
+    state[i] = (int)word;
+  }
+  f = 3;
+  b = 0;
+  for (int i = 0; i < 310; i++) (void)next();
+}
+
+int PbLibcRand::next() {
+  int *state = r + 3;
+  const unsigned v = (unsigned)state[f] + (unsigned)state[b];
+  state[f] = (int)v;
+  const int out = (int)(v >> 1);
+  if (++f >= 31) f = 0;
+  if (++b >= 31) b = 0;
+  return out;
+}
+
 void Particlebot::setVerbosePlacement(bool on) { g_verbosePlacement = on; }
 
 Particlebot::Particlebot(SimParams simparams) : Particlebot(simparams, Engine::Fused, 64.0f) {}
 
-Particlebot::Particlebot(SimParams simparams, Engine engine, float wall) : time(0) {
+Particlebot::Particlebot(SimParams simparams, Engine engine, float wall) : time(0), rng(simparams.seed) {
   params = simparams;
   engineKind = engine;
   if (const char *e = getenv("PB_ENGINE")) {
@@ -188,7 +217,7 @@ void Particlebot::drawDeadBots() {
   for (uint i = 0; i < params.nCells; i++) inds.push_back((int)i);
   int count = 0;
   while (count < params.nDead) {
-    const int i = rand() % inds.size();
+    const int i = rng.next() % inds.size();
     hDead[inds[i]] = 1;
     inds.erase(inds.begin() + i);
     count++;
@@ -463,7 +492,7 @@ void Particlebot::initGrid(uint2 size, float spacing, float jitter, uint nCells)
     for (uint x = 0; x < size.x; x++) {
       const uint i = (y * size.x) + x;
       if (i < nCells) {
-        hPos[i * 2] = (spacing * x) + params.min_radius - xs + (frand() * 2.0f - 1.0f) * jitter;
+        hPos[i * 2] = (spacing * x) + params.min_radius - xs + (frand(rng) * 2.0f - 1.0f) * jitter;
         hPos[i * 2 + 1] = 0;
         hVel[i * 2] = 0.0f;
         hVel[i * 2 + 1] = 0.0f;
@@ -517,7 +546,7 @@ void Particlebot::placeRandom() {
   for (uint i = 1; i < n; i++) {
     if (g_verbosePlacement) printf("Placing %d th disc\n", i);
     if (i == 2) {
-      const int side = rand() % 2;
+      const int side = rng.next() % 2;
       float dx = hPos[2] - hPos[0], dy = hPos[3] - hPos[1];
       const float l = hostLength(dx, dy);
       dy = dy / l;
@@ -533,12 +562,12 @@ void Particlebot::placeRandom() {
     }
     float r = params.min_radius;
     for (;;) {
-      const uint anchor = (uint)rand() % i;
+      const uint anchor = (uint)rng.next() % i;
       if (rejections == maxRejections) {
         rejections = 0;
         r += params.min_radius;
       }
-      float theta = 2 * frand() * kPi;
+      float theta = 2 * frand(rng) * kPi;
       x = hPos[2 * anchor] + 2 * r * cosf(theta);
       y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
       if (grid.crowded(x, y, hPos, touch)) {
@@ -581,7 +610,7 @@ void Particlebot::reset() {
   switch (params.config) {
     case CONFIG_HEX:
       particlebotConfigSize.x = (int)ceilf(powf((float)n, 1.0f / 2.0f));
-      initHexGrid(n, params.min_radius * 2.0f);
+      initHexGrid(n, hexSpacing > 0.0f ? hexSpacing : params.min_radius * 2.0f);
       break;
     case CONFIG_GRID: {
       const float jitter = params.max_radius * 0.01f;

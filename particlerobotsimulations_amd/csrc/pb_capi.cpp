@@ -169,6 +169,7 @@ void *pbHostCreate(const char *cfg_path, const char *overrides, int engine) {
   h->bot = new Particlebot(h->cfg.params, engine ? Particlebot::Engine::Legacy : Particlebot::Engine::Fused,
                            h->cfg.wallHalf());
   h->bot->setExitOnMaxTime(false);
+  h->bot->setHexSpacing(h->cfg.hex_spacing);
   return h;
 }
 
@@ -189,6 +190,12 @@ void pbHostUpdate(void *hv) {
 int pbHostAdvance(void *hv, int nsteps) {
   HostSim *h = (HostSim *)hv;
   return h->bot->advance(h->cfg.timestep, h->cfg.sort_interval, nsteps);
+}
+
+// steps that can run before the next dump row (or the end of the run) is due; >= 1
+int pbHostStepsUntilDump(void *hv, int maxSteps) {
+  HostSim *h = (HostSim *)hv;
+  return h->bot->stepsUntilHostEvent(h->cfg.timestep, h->cfg.dump_interval, maxSteps);
 }
 
 float pbHostTime(void *hv) { return ((HostSim *)hv)->bot->getTime(); }
@@ -233,6 +240,12 @@ int pbHostSetArray(void *hv, int which, const float *data, int start, int count)
   if (which < 0 || which > 4) return -1;
   h->bot->setArray((ParticlebotArray)which, data, start, count);
   return 0;
+}
+
+// n draws of the class's glibc-compatible generator after seeding (for the CPU test against rand())
+void pbHostLibcRandDraws(unsigned seed, int n, int *out) {
+  PbLibcRand g(seed);
+  for (int i = 0; i < n; i++) out[i] = g.next();
 }
 
 unsigned pbHostNumBots(void *hv) { return ((HostSim *)hv)->bot->getParams().nCells; }

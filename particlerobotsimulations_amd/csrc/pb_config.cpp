@@ -66,6 +66,7 @@ PbRunConfig::PbRunConfig() {
   video_filename = "particle_bot_output_video.avi";
   grid_size = 0;
   arena_half = 0.0f;
+  hex_spacing = 0.0f;
   repoint();
 }
 
@@ -174,6 +175,7 @@ void PbRunConfig::setParam(const std::string &name, const std::string &value) {
   // ---- extensions, tried only after every reference key ----
   else if (is("pb_grid_size", 12)) grid_size = (unsigned)l();
   else if (is("pb_arena_half", 13)) arena_half = f();
+  else if (is("pb_hex_spacing", 14)) hex_spacing = f();
   else if (is("pb_placement", 12)) {
     if (value.rfind("hex", 0) == 0) params.config = CONFIG_HEX;
     else if (value.rfind("grid", 0) == 0) params.config = CONFIG_GRID;

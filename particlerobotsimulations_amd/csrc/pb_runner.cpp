@@ -38,7 +38,7 @@ int main(int argc, char **argv) {
   }
   if (!cfg.loadFile(path)) fprintf(stderr, "warning: cannot open %s, running on defaults\n", path.c_str());
   for (auto &kv : sets) cfg.setParam(kv.first, kv.second);
-  srand(cfg.params.seed);
+  srand(cfg.params.seed);  // main.cpp:929 (the class itself draws from a private, identical stream)
   cfg.derive();
 
   FILE *fp = fopen(cfg.csv_filename.c_str(), "w+");
@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
   }
   Particlebot sim(cfg.params, engine, cfg.wallHalf());
   sim.setExitOnMaxTime(false);
+  sim.setHexSpacing(cfg.hex_spacing);
   sim.reset();
   const SimParams &p = sim.getParams();
   for (;;) {
