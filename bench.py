@@ -26,17 +26,30 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALG_BYTES_PER_PARTICLE_STEP = 64.0  # read 36 + write 28
-# Lattice spacing of the headline workload.  SURVEY.md 8(d) proposed exactly 2*min_radius = 0.155
-# (every bot touching six neighbours).  Measured here: that lattice sits inside the constant 2.5 N
-# attraction band (gap < 0.0009, impl.cuh:581-583), implodes, and by step ~400 has expanded into a
-# dilute gas with almost no neighbours left, after which a step costs 10x less -- a benchmark of
-# nothing.  At 0.161 the per-neighbour attraction (A/gap^2 = 1.3 N) stays under the static-friction
-# hold (2*mu*g = 4.4 N, impl.cuh:809-811), the blob stays dense for the whole run (~42 candidate
-# pairs per bot, like the reference's own blobs), and the per-step cost is steady.  The touching
+# Headline workload: SQUARE lattice at pitch 2*min_radius (every bot touches 4 neighbours).
+# SURVEY.md 8(d) proposed a HEXAGONAL lattice at that pitch.  Measured with the oracle: any hexagonal
+# packing is numerically unstable under the reference's own parameters -- six contacts per bot put
+# the explicit tangential damping at 6*shear*dt = 2.4 > 2 -- so it "boils" (speeds of several units/s,
+# contact forces ~1000 N), the touching one first implodes and then expands into a dilute gas with
+# no neighbours left (a step then costs 10x less), and at 10^6 bots it ends in NaN.  A square lattice
+# (4 contacts, 1.6 < 2) is calm and jammed like the reference's random blobs, stays dense for the
+# whole run (~57 candidate pairs per bot) and has a steady per-step cost.  The survey-literal hex
 # lattice is still measured and reported under "survey_literal_lattice".
-RELAXED_SPACING = 0.161
-TOUCHING_SPACING = 0.155
+LATTICE_PITCH = 0.155
 HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def square_lattice(n, pitch):
+    """side x side bots (row-major, bot i at column i % side, row i // side), centred on the origin."""
+    import numpy as np
+    f = np.float32
+    side = int(np.ceil(np.sqrt(n)))
+    i = np.arange(n, dtype=np.int64)
+    half = f((side - 1) * 0.5)
+    pos = np.empty((n, 2), dtype=f)
+    pos[:, 0] = ((i % side).astype(f) - half) * f(pitch)
+    pos[:, 1] = ((i // side).astype(f) - half) * f(pitch)
+    return pos
 
 
 def hex_lattice(n, spacing):
@@ -88,7 +101,7 @@ def workload_params(n_bots, seed):
     return make_params(d)
 
 
-def cpu_baseline(n_bots, spacing=RELAXED_SPACING, budget_s=12.0):
+def cpu_baseline(n_bots, pitch=LATTICE_PITCH, budget_s=12.0):
     """The oracle (our CPU port: the reference has no CPU path) timed on this host's cores on the
     SAME workload, for a bounded number of steps."""
     import numpy as np
@@ -98,7 +111,7 @@ def cpu_baseline(n_bots, spacing=RELAXED_SPACING, budget_s=12.0):
     cores = orclib.usable_cpus()
     orclib.lib().orc_set_num_threads(cores)
     sim = orclib.Sim(P, reset=True, hex=True)
-    sim.set("pos", hex_lattice(n_bots, np.float32(spacing)))
+    sim.set("pos", square_lattice(n_bots, pitch))
     sim.run(1)  # first step: includes the initial sort
     t0 = time.perf_counter()
     steps = 0
@@ -106,7 +119,7 @@ def cpu_baseline(n_bots, spacing=RELAXED_SPACING, budget_s=12.0):
         sim.run(1)
         steps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or steps >= 200:
+        if el > budget_s or steps >= 5000:
             break
     sim.close()
     return {"value": n_bots * steps / el, "unit": "particle-steps/s", "cores": orclib.lib().orc_num_threads(),
@@ -115,29 +128,32 @@ def cpu_baseline(n_bots, spacing=RELAXED_SPACING, budget_s=12.0):
                       f"({el:.1f} s); reported, not optimised"}
 
 
-def make_sim(pb, n, spacing, seed):
+def make_sim(pb, n, pitch, seed, lattice="square"):
     import numpy as np
     sp, keep = workload_params(n, seed=seed)
     sim = pb.Sim(sp, wall_half=240.0, keepalive=keep)
-    pos = hex_lattice(n, np.float32(spacing))
+    pos = square_lattice(n, pitch) if lattice == "square" else hex_lattice(n, np.float32(pitch))
     sim.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
                   phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
     return sim
 
 
 def survey_literal(pb, n, steps, warmup):
-    """The touching lattice exactly as SURVEY.md 8(d) words it, reported beside the headline."""
-    sim = make_sim(pb, n, TOUCHING_SPACING, seed=1)
+    """The hexagonal lattice exactly as SURVEY.md 8(d) words it, reported beside the headline."""
+    sim = make_sim(pb, n, LATTICE_PITCH, seed=1, lattice="hex")
     sim.step(warmup)
     first = min(300, steps)
     d1, ms1 = sim.step_timed(first)
     d2, ms2 = (0, 0.0) if steps <= first else sim.step_timed(steps - first)
+    cx, cy = sim.centroid()
     sim.close()
-    return {"spacing": TOUCHING_SPACING, "steps": steps, "warmup": warmup,
+    return {"lattice": "hexagonal", "pitch": LATTICE_PITCH, "steps": steps, "warmup": warmup,
+            "finite_at_end": bool(cx == cx and cy == cy),
             "value": n * (d1 + d2) / ((ms1 + ms2) * 1e-3), "unit": "particle-steps/s (device time)",
             "us_per_step_first_300": ms1 * 1e3 / max(d1, 1),
             "us_per_step_rest": (ms2 * 1e3 / d2) if d2 else None,
-            "note": "dense only while the lattice implodes; afterwards a dilute gas (see RELAXED_SPACING comment)"}
+            "note": "numerically unstable packing: dense only while it implodes, then a dilute gas / NaN "
+                    "(see the LATTICE_PITCH comment in bench.py)"}
 
 
 def main():
@@ -146,7 +162,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2400)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--bots", type=int, default=1_000_000)
-    ap.add_argument("--spacing", type=float, default=RELAXED_SPACING)
+    ap.add_argument("--pitch", type=float, default=LATTICE_PITCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-survey-literal", action="store_true")
     args = ap.parse_args()
@@ -169,7 +185,7 @@ def main():
         pb.legacy.cudaInit(0, None)  # N > 1: torch.cuda.set_device above already chose this rank's GPU
 
     n = args.bots
-    sim = make_sim(pb, n, args.spacing, seed=1 + rank)
+    sim = make_sim(pb, n, args.pitch, seed=1 + rank)
 
     def barrier():
         sim.synchronize()
@@ -200,6 +216,7 @@ def main():
     else:
         cx, cy = sim.centroid()
         summaries = [[sim.time, cx, cy]]
+    assert cx == cx and cy == cy, "simulation state went NaN: the benchmark workload is invalid"
 
     if rank == 0:
         launches = (s1["fused_launches"] - s0["fused_launches"]) + (s1["plain_launches"] - s0["plain_launches"])
@@ -213,9 +230,9 @@ def main():
             "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic phototaxis arena (BASELINE configs[2]): hex lattice of oscillating "
-                                   f"bots at spacing {args.spacing} (dense for the whole run), one light at "
-                                   "(-230,0), 2048^2 grid, walls +-240, phase_std 0",
+            "config": {"workload": "synthetic phototaxis arena (BASELINE configs[2]): square lattice of oscillating "
+                                   f"bots at pitch {args.pitch} (jammed and dense for the whole run), one light "
+                                   "at (-230,0), 2048^2 grid, walls +-240, phase_std 0",
                        "bots_per_gpu": n, "dt": 0.01, "sort_interval": 180.0,
                        "parallelism": "single arena" if world == 1 else f"{world} independent arenas, one per GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -223,8 +240,8 @@ def main():
                          "kernel": "k_force<FUSE> (forces of step n + radius/integration of step n+1)",
                          "launches": launches, "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * n,
-                         "note": "the kernel is VALU-bound, not HBM-bound: ~42 neighbour pairs per bot, each "
-                                 "with 4 IEEE divisions and 2 IEEE square roots (DESIGN.md 'Roofline')"},
+                         "note": "the kernel is VALU-bound, not HBM-bound: ~50 neighbour pairs per bot, each "
+                                 "with 4 IEEE divisions and 2 IEEE square roots (DESIGN.md section 5)"},
             "device_ms_timed_region": dev_ms,
             "summaries_time_comx_comy": summaries,
         }
@@ -232,7 +249,7 @@ def main():
         if world == 1 and not args.no_survey_literal:
             out["survey_literal_lattice"] = survey_literal(pb, n, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, args.spacing)
+            out["cpu_baseline"] = cpu_baseline(n, args.pitch)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -24,13 +24,15 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--skip", type=int, default=100, help="untimed steps before the first round")
-    ap.add_argument("--spacing", type=float, default=bench.RELAXED_SPACING)
+    ap.add_argument("--pitch", type=float, default=bench.LATTICE_PITCH)
+    ap.add_argument("--lattice", default="square")
     args = ap.parse_args()
     import particlerobotsimulations_amd as pb
     pb.legacy.cudaInit(0, None)
     n = args.bots
     variants = [int(v) for v in args.variants.split(",")]
-    pos = bench.hex_lattice(n, np.float32(args.spacing))
+    pos = (bench.square_lattice(n, args.pitch) if args.lattice == "square"
+           else bench.hex_lattice(n, np.float32(args.pitch)))
     sims = {}
     for v in variants:
         os.environ["PB_FORCE_VARIANT"] = str(v)
