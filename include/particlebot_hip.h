@@ -134,6 +134,21 @@ const char *pbGetLastErrorString(void);
 int pbSimCreate(pbSim **out, const SimParams *params, float wallHalf);
 void pbSimDestroy(pbSim *sim);
 
+/* A BATCH of nsims independent simulations (an ensemble: seeds, sweep points) stepped together by
+ * the same kernel launches: params is an array of nsims blocks.  All members must share nCells,
+ * the grid, max_time, phase_update_interval, control and payload mode (nDead == -1 or not);
+ * everything else (seed, light, obstacles, physics constants) may differ.  pbSimStep & co. advance
+ * every member; the *Of functions address one member; pbSimCreate is the nsims == 1 case and the
+ * un-suffixed state functions address member 0. */
+int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wallHalf);
+int pbSimBatchSize(pbSim *sim, unsigned *nsims, unsigned *nbots);
+int pbSimSetStateOf(pbSim *sim, unsigned member, const float *pos, const float *vel, const float *rad,
+                    const float *phase, const int *dead);
+int pbSimGetStateOf(pbSim *sim, unsigned member, float *pos, float *vel, float *rad, float *phase, int *dead,
+                    float *absForce_a, float *absForce_r);
+/* centre of mass of every member: cxcy[2*k], cxcy[2*k+1]; reduced on the device in a fixed order */
+int pbSimCentroids(pbSim *sim, double *cxcy);
+
 /* Host arrays in ORIGINAL bot order; NULL pointers leave that array unchanged.
  * pos, vel: 2*n floats; rad, phase: n floats; dead: n ints. */
 int pbSimSetState(pbSim *sim, const float *pos, const float *vel, const float *rad, const float *phase,

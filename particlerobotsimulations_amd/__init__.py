@@ -14,7 +14,7 @@ import numpy as np
 from . import _capi
 from ._capi import SimParams, make_params, pbSimStats  # noqa: F401
 
-__all__ = ["Sim", "DeviceArray", "legacy", "SimParams", "make_params", "library_paths", "self_test"]
+__all__ = ["Sim", "Ensemble", "DeviceArray", "legacy", "SimParams", "make_params", "library_paths", "self_test"]
 
 
 def self_test(div_samples=1 << 32):
@@ -226,3 +226,48 @@ class Sim:
 
     def set_resort_every_step(self, on):
         _capi.check(_capi.lib().pbSimSetResortEveryStep(self._h, 1 if on else 0))
+
+
+class Ensemble(Sim):
+    """A batch of independent simulations of equal size stepped by the same launches
+    (pbSimCreateBatch): seeds of a Monte-Carlo run, points of a parameter sweep."""
+
+    def __init__(self, params_list, wall_half=0.0, keepalive=None):
+        self._keep = keepalive
+        self.nsims = len(params_list)
+        arr = (SimParams * self.nsims)(*params_list)
+        self.params = params_list[0]
+        self.n = int(params_list[0].nCells)
+        h = C.c_void_p()
+        _capi.check(_capi.lib().pbSimCreateBatch(C.byref(h), arr, self.nsims, float(wall_half)), "pbSimCreateBatch")
+        self._h = h
+
+    def set_state_of(self, member, pos=None, vel=None, rad=None, phase=None, dead=None):
+        n = self.n
+        pos = self._in(pos, np.float32, 2 * n)
+        vel = self._in(vel, np.float32, 2 * n)
+        rad = self._in(rad, np.float32, n)
+        phase = self._in(phase, np.float32, n)
+        dead = self._in(dead, np.int32, n)
+        _capi.check(_capi.lib().pbSimSetStateOf(self._h, int(member), _capi.np_ptr(pos), _capi.np_ptr(vel),
+                                                _capi.np_ptr(rad), _capi.np_ptr(phase), _capi.np_ptr(dead)),
+                    "pbSimSetStateOf")
+
+    def get_state_of(self, member):
+        n = self.n
+        out = {
+            "pos": np.empty((n, 2), np.float32), "vel": np.empty((n, 2), np.float32),
+            "rad": np.empty(n, np.float32), "phase": np.empty(n, np.float32),
+            "dead": np.empty(n, np.int32), "absForce_a": np.empty(n, np.float32),
+            "absForce_r": np.empty(n, np.float32),
+        }
+        _capi.check(_capi.lib().pbSimGetStateOf(self._h, int(member), *[_capi.np_ptr(out[k]) for k in
+                                                                        ("pos", "vel", "rad", "phase", "dead",
+                                                                         "absForce_a", "absForce_r")]),
+                    "pbSimGetStateOf")
+        return out
+
+    def centroids(self):
+        out = np.empty((self.nsims, 2), np.float64)
+        _capi.check(_capi.lib().pbSimCentroids(self._h, out.ctypes.data_as(C.POINTER(C.c_double))), "pbSimCentroids")
+        return out

@@ -101,6 +101,11 @@ SYMBOLS = {
     "pbGetLastErrorString": (C.c_char_p, []),
     "pbSimCreate": (_I, [C.POINTER(_VP), C.POINTER(SimParams), _F]),
     "pbSimDestroy": (None, [_VP]),
+    "pbSimCreateBatch": (_I, [C.POINTER(_VP), C.POINTER(SimParams), _I, _F]),
+    "pbSimBatchSize": (_I, [_VP, C.POINTER(_U), C.POINTER(_U)]),
+    "pbSimSetStateOf": (_I, [_VP, _U, _VP, _VP, _VP, _VP, _VP]),
+    "pbSimGetStateOf": (_I, [_VP, _U] + [_VP] * 7),
+    "pbSimCentroids": (_I, [_VP, C.POINTER(C.c_double)]),
     "pbSimSetState": (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "pbSimGetState": (_I, [_VP] * 8),
     "pbSimSetTime": (_I, [_VP, _F]),

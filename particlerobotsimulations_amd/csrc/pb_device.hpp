@@ -28,6 +28,7 @@ struct PbDevParams {
   float min_radius, max_radius, rise_period;
   int32_t Nx;
   uint32_t light_shadow, constrained_contraction, seed;
+  float phase_std;
   float wallHalf;
   int32_t nobstacles;
   float x1obs[PB_MAX_OBSTACLES], x2obs[PB_MAX_OBSTACLES], y1obs[PB_MAX_OBSTACLES], y2obs[PB_MAX_OBSTACLES];
@@ -66,6 +67,7 @@ static inline void pbFlattenParams(PbDevParams &d, const SimParams &p, float wal
   d.light_shadow = p.light_shadow;
   d.constrained_contraction = p.constrained_contraction;
   d.seed = p.seed;
+  d.phase_std = p.phase_std;
   d.wallHalf = wallHalf > 0.0f ? wallHalf : 64.0f;
   d.nobstacles = p.nobstacles < 0 ? 0 : (p.nobstacles > PB_MAX_OBSTACLES ? PB_MAX_OBSTACLES : p.nobstacles);
   d.n_cir = p.n_cir_obstacles < 0 ? 0

@@ -20,9 +20,15 @@
 //    sorted array, so a tile's neighbour rows (+-2 grid rows) are in the same XCD's L2.
 //  * posrad = (x, y, radius, attraction factor): one 16-byte load per neighbour; the payload's
 //    attractionFactor (impl.cuh:629-633,640-644) rides in .w so the pair loop has no index lookups.
+//  * A pbSim is a BATCH of nsims >= 1 independent simulations of equal size stepped by the same
+//    launches (blockIdx.y = simulation): one parameter block per simulation in device memory, all
+//    arrays concatenated (slot = sim*n + local), sort keys = sim*numCells + cell hash, one dense
+//    cell table per simulation.  An ensemble of small blobs costs one launch per timestep, not one
+//    per simulation; a single arena is the nsims == 1 case.
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "particlebot_hip.h"
 #include "pb_device.hpp"
@@ -53,12 +59,15 @@ inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // ---- kernels ------------------------------------------------------------------------------
 
 // stand-alone radius actuation + integration for one step (impl.cuh:124-181 + :53-103), in place
-__global__ __launch_bounds__(TILE) void k_state(PbDevParams P, float4 *__restrict__ pr, float2 *__restrict__ vel,
-                                                const float *__restrict__ phase, const int *__restrict__ dead,
-                                                const float *__restrict__ absA, const float *__restrict__ absR,
-                                                uint32_t n, float time, float dt, int doRadius) {
-  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
-  if (s >= n) return;
+__global__ __launch_bounds__(TILE) void k_state(const PbDevParams *__restrict__ params, float4 *__restrict__ pr,
+                                                float2 *__restrict__ vel, const float *__restrict__ phase,
+                                                const int *__restrict__ dead, const float *__restrict__ absA,
+                                                const float *__restrict__ absR, uint32_t n, float time, float dt,
+                                                int doRadius) {
+  const PbDevParams &P = params[blockIdx.y];
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t s = blockIdx.y * n + l;
   float4 q = pr[s];
   float2 v = vel[s];
   if (doRadius) q.z = pbActuate(P, q.z, phase[s], dead[s], absA[s], absR[s], time, dt);
@@ -73,19 +82,23 @@ __global__ __launch_bounds__(TILE) void k_state(PbDevParams P, float4 *__restric
 // FASTOK: the simulation passed pbFastMathAllowed, so waves whose lanes all pass
 // pbLaneFastMathOk may use the exact fast sqrt/division forms.
 template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK>
-__global__ __launch_bounds__(TILE) void k_force(PbDevParams P, const float4 *__restrict__ prIn,
-                                                const float2 *__restrict__ velIn, float4 *__restrict__ prOut,
-                                                float2 *__restrict__ velOut, const float *__restrict__ phase,
-                                                const int *__restrict__ dead, float *__restrict__ absA,
-                                                float *__restrict__ absR, const uint32_t *__restrict__ orig,
-                                                const uint32_t *__restrict__ cellS, uint32_t n, float dt,
-                                                float timeNext, int doRadiusNext) {
-  // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (round-robin dispatch); give
-  // each XCD one contiguous eighth of the tiles.  gridDim.x is a multiple of 8.
-  const uint32_t per = gridDim.x >> 3;
-  const uint32_t tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-  const uint32_t s = tile * TILE + threadIdx.x;
-  if (s >= n) return;
+__global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ params,
+                                                const float4 *__restrict__ prIn, const float2 *__restrict__ velIn,
+                                                float4 *__restrict__ prOut, float2 *__restrict__ velOut,
+                                                const float *__restrict__ phase, const int *__restrict__ dead,
+                                                float *__restrict__ absA, float *__restrict__ absR,
+                                                const uint32_t *__restrict__ orig,
+                                                const uint32_t *__restrict__ cellSAll, uint32_t n, float dt,
+                                                float timeNext, int doRadiusNext, uint32_t perXcd) {
+  const PbDevParams &P = params[blockIdx.y];
+  // XCD-aware tile order (large simulations): workgroups b, b+8, b+16, ... share an XCD
+  // (round-robin dispatch); give each XCD one contiguous eighth of the tiles (gridDim.x = 8*perXcd).
+  // perXcd == 0: plain order (small simulations, a handful of tiles each).
+  const uint32_t tile = perXcd ? (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t l = tile * TILE + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t s = blockIdx.y * n + l;  // global slot; the cell table holds global slots too
+  const uint32_t *__restrict__ cellS = cellSAll + (size_t)blockIdx.y * (P.numCells + 1u);
 
   const float4 me = prIn[s];
   float2 v = velIn[s];
@@ -172,15 +185,18 @@ __global__ __launch_bounds__(TILE) void k_force(PbDevParams P, const float4 *__r
   absR[s] = F.fr;
 }
 
-// re-sort step 1: hash in ORIGINAL order (calcHashD, impl.cuh:446-465) + inverse permutation
-__global__ __launch_bounds__(TILE) void k_hash(PbDevParams P, const float4 *__restrict__ pr,
+// re-sort step 1: hash in ORIGINAL order (calcHashD, impl.cuh:446-465) + inverse permutation.
+// Keys carry the simulation number above the cell hash so one stable sort keeps simulations apart.
+__global__ __launch_bounds__(TILE) void k_hash(const PbDevParams *__restrict__ params, const float4 *__restrict__ pr,
                                                const uint32_t *__restrict__ orig, uint32_t *__restrict__ keys,
                                                uint32_t *__restrict__ vals, uint32_t *__restrict__ slotOf, uint32_t n) {
-  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
-  if (s >= n) return;
+  const PbDevParams &P = params[blockIdx.y];
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t base = blockIdx.y * n, s = base + l;
   const float4 q = pr[s];
-  const uint32_t o = orig[s];
-  keys[o] = pbHash(P, pbCellX(P, q.x), pbCellY(P, q.y));
+  const uint32_t o = base + orig[s];
+  keys[o] = blockIdx.y * P.numCells + pbHash(P, pbCellX(P, q.x), pbCellY(P, q.y));
   vals[o] = o;
   slotOf[o] = s;
 }
@@ -195,9 +211,10 @@ __global__ __launch_bounds__(TILE) void k_permute(const uint32_t *__restrict__ n
                                                   int *__restrict__ deadOut, float *__restrict__ absAOut,
                                                   float *__restrict__ absROut, uint32_t *__restrict__ origOut,
                                                   uint32_t n) {
-  const uint32_t t = blockIdx.x * TILE + threadIdx.x;
-  if (t >= n) return;
-  const uint32_t o = newOrig[t];
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t base = blockIdx.y * n, t = base + l;
+  const uint32_t o = newOrig[t];  // global original index; stays inside this simulation's block
   const uint32_t src = slotOf[o];
   prOut[t] = prIn[src];
   velOut[t] = velIn[src];
@@ -205,32 +222,36 @@ __global__ __launch_bounds__(TILE) void k_permute(const uint32_t *__restrict__ n
   deadOut[t] = deadIn[src];
   absAOut[t] = absAIn[src];
   absROut[t] = absRIn[src];
-  origOut[t] = o;
+  origOut[t] = o - base;
 }
 
-// re-sort step 4: cellS[c] = number of bots whose hash is < c (lower bound in the sorted keys)
-__global__ __launch_bounds__(TILE) void k_cell_scan(const uint32_t *__restrict__ sortedKeys, uint32_t n,
+// re-sort step 4: cellS[sim][c] = number of bots (all simulations before + this one) whose key is
+// below sim*numCells + c: a lower bound in the sorted keys, as a GLOBAL slot index
+__global__ __launch_bounds__(TILE) void k_cell_scan(const uint32_t *__restrict__ sortedKeys, uint32_t total,
                                                     uint32_t *__restrict__ cellS, uint32_t numCells) {
   const uint32_t c = blockIdx.x * TILE + threadIdx.x;
   if (c > numCells) return;
-  uint32_t lo = 0, hi = n;
+  const uint32_t want = blockIdx.y * numCells + c;
+  uint32_t lo = 0, hi = total;
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (sortedKeys[mid] < c) lo = mid + 1;
+    if (sortedKeys[mid] < want) lo = mid + 1;
     else hi = mid;
   }
-  cellS[c] = lo;
+  cellS[(size_t)blockIdx.y * (numCells + 1u) + c] = lo;
 }
 
-// min over bots of the squared distance to the light, as the host loop of particlebot.cpp:215-228
-// squares it: powf(light-x,2)+powf(light-y,2).  Non-negative floats order like their bit patterns,
-// so an integer atomicMin is exact and order-independent.
-__global__ __launch_bounds__(TILE) void k_min_dist2(PbDevParams P, const float4 *__restrict__ pr, uint32_t n,
+// min over a simulation's bots of the squared distance to the light, as the host loop of
+// particlebot.cpp:215-228 squares it: powf(light-x,2)+powf(light-y,2).  Non-negative floats order
+// like their bit patterns, so an integer atomicMin is exact and order-independent.
+__global__ __launch_bounds__(TILE) void k_min_dist2(const PbDevParams *__restrict__ params,
+                                                    const float4 *__restrict__ pr, uint32_t n,
                                                     uint32_t *__restrict__ outBits) {
-  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
+  const PbDevParams &P = params[blockIdx.y];
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
   uint32_t bits = 0x7f800000u;  // +inf
-  if (s < n) {
-    const float4 q = pr[s];
+  if (l < n) {
+    const float4 q = pr[blockIdx.y * n + l];
     const float dx = P.light_x - q.x, dy = P.light_y - q.y;
     bits = __float_as_uint(dx * dx + dy * dy);
   }
@@ -239,33 +260,39 @@ __global__ __launch_bounds__(TILE) void k_min_dist2(PbDevParams P, const float4 
     const uint32_t o = __shfl_xor(bits, d, 64);
     bits = o < bits ? o : bits;
   }
-  if ((threadIdx.x & 63u) == 0u) atomicMin(outBits, bits);
+  if ((threadIdx.x & 63u) == 0u) atomicMin(&outBits[blockIdx.y], bits);
 }
 
 // updatePhase (impl.cuh:264-290) + add_normal_noise (impl.cuh:43-51) in slot order
-__global__ __launch_bounds__(TILE) void k_phase(PbDevParams P, const float4 *__restrict__ pr,
+__global__ __launch_bounds__(TILE) void k_phase(const PbDevParams *__restrict__ params, const float4 *__restrict__ pr,
                                                 const uint32_t *__restrict__ orig, float *__restrict__ phase,
-                                                uint32_t n, float spacing, float min_d, float std, uint32_t draw) {
-  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
-  if (s >= n) return;
+                                                uint32_t n, const float *__restrict__ minD, uint32_t draw) {
+  const PbDevParams &P = params[blockIdx.y];
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t s = blockIdx.y * n + l;
   const float4 q = pr[s];
-  float ph = pbPhase(P, q.x, q.y, spacing, min_d, phase[s]);
-  if (std != 0.0f) {
-    const float noise = std * pbNormal(P.seed, orig[s], draw);
+  const float spacing = 2.0f * P.min_radius;  // particlebot.cpp:229
+  float ph = pbPhase(P, q.x, q.y, spacing, minD[blockIdx.y], phase[s]);
+  if (P.phase_std != 0.0f) {
+    const float noise = P.phase_std * pbNormal(P.seed, orig[s], draw);
     ph += noise;
   }
   phase[s] = ph;
 }
 
-// host arrays (original order, staged on the device) -> slot order
-__global__ __launch_bounds__(TILE) void k_set_state(PbDevParams P, const uint32_t *__restrict__ orig,
-                                                    float4 *__restrict__ pr, float2 *__restrict__ vel,
-                                                    float *__restrict__ phase, int *__restrict__ dead,
-                                                    const float2 *__restrict__ inPos, const float2 *__restrict__ inVel,
-                                                    const float *__restrict__ inRad, const float *__restrict__ inPhase,
-                                                    const int *__restrict__ inDead, uint32_t n) {
-  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
-  if (s >= n) return;
+// host arrays of ONE simulation (original order, staged on the device) -> slot order
+__global__ __launch_bounds__(TILE) void k_set_state(const PbDevParams *__restrict__ params, uint32_t sim,
+                                                    const uint32_t *__restrict__ orig, float4 *__restrict__ pr,
+                                                    float2 *__restrict__ vel, float *__restrict__ phase,
+                                                    int *__restrict__ dead, const float2 *__restrict__ inPos,
+                                                    const float2 *__restrict__ inVel, const float *__restrict__ inRad,
+                                                    const float *__restrict__ inPhase, const int *__restrict__ inDead,
+                                                    uint32_t n) {
+  const PbDevParams &P = params[sim];
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t s = sim * n + l;
   const uint32_t o = orig[s];
   float4 q = pr[s];
   if (inPos) {
@@ -281,17 +308,18 @@ __global__ __launch_bounds__(TILE) void k_set_state(PbDevParams P, const uint32_
   if (inDead) dead[s] = inDead[o];
 }
 
-// slot order -> original order
-__global__ __launch_bounds__(TILE) void k_get_state(const uint32_t *__restrict__ orig, const float4 *__restrict__ pr,
-                                                    const float2 *__restrict__ vel, const float *__restrict__ phase,
-                                                    const int *__restrict__ dead, const float *__restrict__ absA,
-                                                    const float *__restrict__ absR, float2 *__restrict__ outPos,
-                                                    float2 *__restrict__ outVel, float *__restrict__ outRad,
-                                                    float *__restrict__ outPhase, int *__restrict__ outDead,
-                                                    float *__restrict__ outAbsA, float *__restrict__ outAbsR,
-                                                    uint32_t n) {
-  const uint32_t s = blockIdx.x * TILE + threadIdx.x;
-  if (s >= n) return;
+// slot order -> original order, ONE simulation
+__global__ __launch_bounds__(TILE) void k_get_state(uint32_t sim, const uint32_t *__restrict__ orig,
+                                                    const float4 *__restrict__ pr, const float2 *__restrict__ vel,
+                                                    const float *__restrict__ phase, const int *__restrict__ dead,
+                                                    const float *__restrict__ absA, const float *__restrict__ absR,
+                                                    float2 *__restrict__ outPos, float2 *__restrict__ outVel,
+                                                    float *__restrict__ outRad, float *__restrict__ outPhase,
+                                                    int *__restrict__ outDead, float *__restrict__ outAbsA,
+                                                    float *__restrict__ outAbsR, uint32_t n) {
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t s = sim * n + l;
   const uint32_t o = orig[s];
   const float4 q = pr[s];
   outPos[o] = make_float2(q.x, q.y);
@@ -304,19 +332,30 @@ __global__ __launch_bounds__(TILE) void k_get_state(const uint32_t *__restrict__
 }
 
 __global__ __launch_bounds__(TILE) void k_iota(uint32_t *__restrict__ a, uint32_t n) {
-  const uint32_t i = blockIdx.x * TILE + threadIdx.x;
-  if (i < n) a[i] = i;
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  if (l < n) a[blockIdx.y * n + l] = l;
 }
 
-// centre of mass in ORIGINAL index order, fixed summation tree: per-workgroup partial sums of
-// 256 consecutive bots (double), then one workgroup adds the partials in order.
+// Centre of mass of every simulation in ORIGINAL index order with a fixed summation tree:
+// positions scattered to original order, per-workgroup partial sums of 256 consecutive bots
+// (double), then one wave per simulation adds its partials in order.
+__global__ __launch_bounds__(TILE) void k_com_scatter(const uint32_t *__restrict__ orig,
+                                                      const float4 *__restrict__ pr, float2 *__restrict__ posOrig,
+                                                      uint32_t n) {
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t s = blockIdx.y * n + l;
+  const float4 q = pr[s];
+  posOrig[blockIdx.y * n + orig[s]] = make_float2(q.x, q.y);
+}
+
 __global__ __launch_bounds__(TILE) void k_com_partial(const float2 *__restrict__ posOrig, uint32_t n,
                                                       double2 *__restrict__ partial) {
   __shared__ double2 sh[TILE];
-  const uint32_t i = blockIdx.x * TILE + threadIdx.x;
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
   double2 v = make_double2(0.0, 0.0);
-  if (i < n) {
-    const float2 p = posOrig[i];
+  if (l < n) {
+    const float2 p = posOrig[blockIdx.y * n + l];
     v = make_double2((double)p.x, (double)p.y);
   }
   sh[threadIdx.x] = v;
@@ -328,17 +367,25 @@ __global__ __launch_bounds__(TILE) void k_com_partial(const float2 *__restrict__
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+  if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = sh[0];
 }
 
-__global__ void k_com_final(const double2 *__restrict__ partial, uint32_t nb, uint32_t n, double2 *__restrict__ out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// one 64-lane wave per simulation: lane k sums partials k, k+64, ... in order, then a fixed
+// shuffle tree combines the 64 lane sums
+__global__ __launch_bounds__(64) void k_com_final(const double2 *__restrict__ partial, uint32_t nb, uint32_t n,
+                                                  double2 *__restrict__ out) {
   double sx = 0.0, sy = 0.0;
-  for (uint32_t b = 0; b < nb; b++) {
-    sx += partial[b].x;
-    sy += partial[b].y;
+  for (uint32_t b = threadIdx.x; b < nb; b += 64u) {
+    const double2 p = partial[blockIdx.x * nb + b];
+    sx += p.x;
+    sy += p.y;
   }
-  out[0] = make_double2(sx / (double)n, sy / (double)n);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    sx += __shfl_xor(sx, d, 64);
+    sy += __shfl_xor(sy, d, 64);
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = make_double2(sx / (double)n, sy / (double)n);
 }
 
 // ---- self-test of the fast exact math (pbSelfTest) ------------------------------------------
@@ -407,9 +454,10 @@ __global__ __launch_bounds__(256) void k_selftest_div(unsigned long long samples
 // ---- the object -----------------------------------------------------------------------------
 
 struct pbSim {
-  PbDevParams P;
-  SimParams host;
-  uint32_t n = 0;
+  std::vector<PbDevParams> hP;  // one parameter block per simulation
+  PbDevParams *dP = nullptr;
+  SimParams host;  // schedule-relevant fields (shared by the batch): max_time, phase_update_interval, control
+  uint32_t nsims = 1, n = 0, total = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -419,21 +467,25 @@ struct pbSim {
   int *dead[2] = {nullptr, nullptr};
   float *absA[2] = {nullptr, nullptr};
   float *absR[2] = {nullptr, nullptr};
-  uint32_t *orig[2] = {nullptr, nullptr};
-  int cur = 0;  // which copy of every array is live
+  uint32_t *orig[2] = {nullptr, nullptr};  // LOCAL original index of each slot
+  int cur = 0;                             // which copy of every array is live
 
-  uint32_t *cellS = nullptr;
+  uint32_t *cellS = nullptr;  // nsims x (numCells+1), global slot indices
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *slotOf = nullptr;
-  uint32_t *dMin = nullptr;
-  uint32_t *hMin = nullptr;  // pinned
+  uint32_t *dMin = nullptr;  // nsims
+  float *dMinD = nullptr;    // nsims
+  uint32_t *hMin = nullptr;  // pinned, nsims
+  float *hMinD = nullptr;    // pinned, nsims
   char *stage = nullptr;     // 36 n bytes: pos 8n | vel 8n | rad 4n | phase 4n | dead 4n | absA 4n | absR 4n
+  float2 *comPos = nullptr;  // total
   double2 *comPartial = nullptr, *comOut = nullptr;
-  double2 *hCom = nullptr;  // pinned
+  double2 *hCom = nullptr;  // pinned, nsims
 
   float time = 0.0f;
   uint32_t phaseDraws = 0;
   bool haveCells = false;
   bool resortEveryStep = false;
+  bool payload = false, fastOk = false;
   int variant = 2;  // force kernel: 0 reference-shaped branches, 1 branch-free, 2 (default) + fast exact math
   pbSimStats stats{};
 };
@@ -445,20 +497,25 @@ inline bool gate(float t, float interval, float dt) {
   return t - interval * floorf(t / interval) < dt;
 }
 
+inline dim3 gridOf(const pbSim *S) { return dim3(cdiv(S->n, TILE), S->nsims); }
+
 template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK>
-void launchForceT(pbSim *S, dim3 grid, int c, int o, float dt, float tNext, int doRadiusNext) {
-  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK>), grid, dim3(TILE), 0, S->stream, S->P, S->pr[c], S->vel[c],
-                     S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c], S->cellS,
-                     S->n, dt, tNext, doRadiusNext);
+void launchForceT(pbSim *S, int c, int o, float dt, float tNext, int doRadiusNext) {
+  const uint32_t tiles = cdiv(S->n, TILE);
+  // XCD-aware order only pays when a simulation spans many tiles
+  const uint32_t perXcd = tiles >= 64u ? cdiv(tiles, 8u) : 0u;
+  const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
+  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK>), grid, dim3(TILE), 0, S->stream, S->dP, S->pr[c],
+                     S->vel[c], S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c],
+                     S->cellS, S->n, dt, tNext, doRadiusNext, perXcd);
 }
 
-void launchForce(pbSim *S, bool fuse, dim3 grid, int c, int o, float dt, float tNext, int doRadiusNext) {
-  const bool payload = (S->P.nDead == -1);
+void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext) {
+  const bool payload = S->payload;
   // variant 0: reference-shaped branches; 1: branch-free; 2 (default): branch-free + fast exact math
-  const int kind = S->variant == 0 ? 0 : (S->variant == 1 || !pbFastMathAllowed(S->P)) ? 1 : 2;
+  const int kind = S->variant == 0 ? 0 : (S->variant == 1 || !S->fastOk) ? 1 : 2;
 #define PB_CASE(F, PL, K, FL, FA) \
-  if (fuse == F && payload == PL && kind == K) \
-    return launchForceT<F, PL, FL, FA>(S, grid, c, o, dt, tNext, doRadiusNext);
+  if (fuse == F && payload == PL && kind == K) return launchForceT<F, PL, FL, FA>(S, c, o, dt, tNext, doRadiusNext);
   PB_CASE(true, true, 0, false, false)
   PB_CASE(true, true, 1, true, false)
   PB_CASE(true, true, 2, true, true)
@@ -477,17 +534,18 @@ void launchForce(pbSim *S, bool fuse, dim3 grid, int c, int o, float dt, float t
 int resort(pbSim *S) {
   const uint32_t n = S->n;
   const int c = S->cur, o = c ^ 1;
-  const dim3 g(cdiv(n, TILE)), b(TILE);
-  hipLaunchKernelGGL(k_hash, g, b, 0, S->stream, S->P, S->pr[c], S->orig[c], S->keys[0], S->vals[0], S->slotOf, n);
+  const dim3 g = gridOf(S), b(TILE);
+  hipLaunchKernelGGL(k_hash, g, b, 0, S->stream, S->dP, S->pr[c], S->orig[c], S->keys[0], S->vals[0], S->slotOf, n);
   hipError_t e;
-  const int where = pbRadixSortPairs(S->keys[0], S->vals[0], S->keys[1], S->vals[1], S->hist, n,
-                                     pbKeyBits(S->P.numCells), S->stream, &e);
+  const int bits = pbKeyBits(S->hP[0].numCells) + (S->nsims > 1 ? pbKeyBits(S->nsims) : 0);
+  const int where =
+      pbRadixSortPairs(S->keys[0], S->vals[0], S->keys[1], S->vals[1], S->hist, S->total, bits, S->stream, &e);
   if (where < 0) PB_TRY(e);
   hipLaunchKernelGGL(k_permute, g, b, 0, S->stream, S->vals[where], S->slotOf, S->pr[c], S->vel[c], S->phase[c],
                      S->dead[c], S->absA[c], S->absR[c], S->pr[o], S->vel[o], S->phase[o], S->dead[o], S->absA[o],
                      S->absR[o], S->orig[o], n);
-  hipLaunchKernelGGL(k_cell_scan, dim3(cdiv(S->P.numCells + 1u, TILE)), b, 0, S->stream, S->keys[where], n, S->cellS,
-                     S->P.numCells);
+  hipLaunchKernelGGL(k_cell_scan, dim3(cdiv(S->hP[0].numCells + 1u, TILE), S->nsims), b, 0, S->stream,
+                     S->keys[where], S->total, S->cellS, S->hP[0].numCells);
   PB_TRY(hipGetLastError());
   S->cur = o;
   S->haveCells = true;
@@ -496,32 +554,35 @@ int resort(pbSim *S) {
 }
 
 int phaseUpdate(pbSim *S) {
-  // particlebot.cpp:212-237.  The min distance goes back to the host (4 bytes) because the
-  // reference takes its square root with glibc powf there (:219); max_d is unused by the kernel.
+  // particlebot.cpp:212-237.  Each simulation's min distance goes back to the host (4 bytes each)
+  // because the reference takes its square root with glibc powf there (:219); max_d is unused.
   const uint32_t n = S->n;
   const int c = S->cur;
-  const dim3 g(cdiv(n, TILE)), b(TILE);
-  PB_TRY(hipMemsetAsync(S->dMin, 0xff, sizeof(uint32_t), S->stream));
-  hipLaunchKernelGGL(k_min_dist2, g, b, 0, S->stream, S->P, S->pr[c], n, S->dMin);
-  PB_TRY(hipMemcpyAsync(S->hMin, S->dMin, sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream));
+  const dim3 g = gridOf(S), b(TILE);
+  PB_TRY(hipMemsetAsync(S->dMin, 0xff, sizeof(uint32_t) * S->nsims, S->stream));
+  hipLaunchKernelGGL(k_min_dist2, g, b, 0, S->stream, S->dP, S->pr[c], n, S->dMin);
+  PB_TRY(hipMemcpyAsync(S->hMin, S->dMin, sizeof(uint32_t) * S->nsims, hipMemcpyDeviceToHost, S->stream));
   PB_TRY(hipStreamSynchronize(S->stream));
-  float minD2;
-  memcpy(&minD2, S->hMin, sizeof(float));
-  const float min_d = powf(minD2, 0.5f);
-  const float spacing = 2.0f * S->host.min_radius;
-  const float std = S->host.phase_std;
-  hipLaunchKernelGGL(k_phase, g, b, 0, S->stream, S->P, S->pr[c], S->orig[c], S->phase[c], n, spacing, min_d, std,
+  for (uint32_t k = 0; k < S->nsims; k++) {
+    float minD2;
+    memcpy(&minD2, &S->hMin[k], sizeof(float));
+    S->hMinD[k] = powf(minD2, 0.5f);
+  }
+  PB_TRY(hipMemcpyAsync(S->dMinD, S->hMinD, sizeof(float) * S->nsims, hipMemcpyHostToDevice, S->stream));
+  hipLaunchKernelGGL(k_phase, g, b, 0, S->stream, S->dP, S->pr[c], S->orig[c], S->phase[c], n, S->dMinD,
                      S->phaseDraws);
   PB_TRY(hipGetLastError());
-  if (std != 0.0f) S->phaseDraws++;
+  // the draw counter advances when any simulation draws; simulations with phase_std == 0 skip it
+  bool anyNoise = false;
+  for (const PbDevParams &p : S->hP) anyNoise = anyNoise || p.phase_std != 0.0f;
+  if (anyNoise) S->phaseDraws++;
   S->stats.phase_updates++;
   return PB_OK;
 }
 
 int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
   const uint32_t n = S->n;
-  const dim3 gA(cdiv(n, TILE)), b(TILE);
-  const dim3 gF(cdiv(cdiv(n, TILE), 8) * 8);
+  const dim3 gA = gridOf(S), b(TILE);
   const float pui = S->host.phase_update_interval;
   const bool lightWave = (S->host.control == LIGHT_WAVE);
   bool ahead = false;  // true: radius+integration of the coming step are already applied
@@ -535,7 +596,7 @@ int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
         if (rc) return rc;
       }
       const int c = S->cur;
-      hipLaunchKernelGGL(k_state, gA, b, 0, S->stream, S->P, S->pr[c], S->vel[c], S->phase[c], S->dead[c],
+      hipLaunchKernelGGL(k_state, gA, b, 0, S->stream, S->dP, S->pr[c], S->vel[c], S->phase[c], S->dead[c],
                          S->absA[c], S->absR[c], n, t, dt, (int)(lightWave && t >= 0));
       S->stats.state_launches++;
     }
@@ -553,7 +614,7 @@ int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
       if (rc) return rc;
     }
     const int c = S->cur, o = c ^ 1;
-    launchForce(S, fuse, gF, c, o, dt, tNext, (int)(fuse && lightWave && tNext >= 0));
+    launchForce(S, fuse, c, o, dt, tNext, (int)(fuse && lightWave && tNext >= 0));
     if (fuse) S->stats.fused_launches++;
     else S->stats.plain_launches++;
     // pr/vel moved to the other copy; the remaining arrays did not.  Swap just those two.
@@ -571,6 +632,18 @@ int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
   }
   PB_TRY(hipGetLastError());
   if (done) *done = k;
+  return PB_OK;
+}
+
+int gatherToStage(pbSim *S, uint32_t sim) {
+  const size_t n = S->n;
+  char *st = S->stage;
+  const int c = S->cur;
+  hipLaunchKernelGGL(k_get_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, sim, S->orig[c], S->pr[c],
+                     S->vel[c], S->phase[c], S->dead[c], S->absA[c], S->absR[c], (float2 *)st, (float2 *)(st + 8 * n),
+                     (float *)(st + 16 * n), (float *)(st + 20 * n), (int *)(st + 24 * n), (float *)(st + 28 * n),
+                     (float *)(st + 32 * n), S->n);
+  PB_TRY(hipGetLastError());
   return PB_OK;
 }
 
@@ -594,14 +667,18 @@ void pbSimDestroy(pbSim *S) {
     (void)hipFree(S->keys[i]);
     (void)hipFree(S->vals[i]);
   }
+  (void)hipFree(S->dP);
   (void)hipFree(S->cellS);
   (void)hipFree(S->hist);
   (void)hipFree(S->slotOf);
   (void)hipFree(S->dMin);
+  (void)hipFree(S->dMinD);
   (void)hipFree(S->stage);
+  (void)hipFree(S->comPos);
   (void)hipFree(S->comPartial);
   (void)hipFree(S->comOut);
   if (S->hMin) (void)hipHostFree(S->hMin);
+  if (S->hMinD) (void)hipHostFree(S->hMinD);
   if (S->hCom) (void)hipHostFree(S->hCom);
   if (S->ev0) (void)hipEventDestroy(S->ev0);
   if (S->ev1) (void)hipEventDestroy(S->ev1);
@@ -609,19 +686,35 @@ void pbSimDestroy(pbSim *S) {
   delete S;
 }
 
-int pbSimCreate(pbSim **out, const SimParams *params, float wallHalf) {
-  if (!out || !params) {
-    g_lastError = "pbSimCreate: null argument";
+int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wallHalf) {
+  if (!out || !params || nsims < 1) {
+    g_lastError = "pbSimCreateBatch: null argument or nsims < 1";
     return PB_ERR_ARG;
   }
   *out = nullptr;
-  const uint32_t gx = params->gridSize.x, gy = params->gridSize.y;
-  if (gx < 8 || gy < 8 || (gx & (gx - 1)) || (gy & (gy - 1)) || params->numCells != gx * gy) {
+  const uint32_t gx = params[0].gridSize.x, gy = params[0].gridSize.y;
+  if (gx < 8 || gy < 8 || (gx & (gx - 1)) || (gy & (gy - 1)) || params[0].numCells != gx * gy) {
     g_lastError = "pbSimCreate: gridSize must be a power of two >= 8 per axis and numCells = x*y";
     return PB_ERR_ARG;
   }
-  if (params->nCells == 0) {
+  if (params[0].nCells == 0) {
     g_lastError = "pbSimCreate: nCells must be > 0";
+    return PB_ERR_ARG;
+  }
+  for (int k = 1; k < nsims; k++) {
+    const SimParams &a = params[0], &b = params[k];
+    if (a.nCells != b.nCells || a.gridSize.x != b.gridSize.x || a.gridSize.y != b.gridSize.y ||
+        a.numCells != b.numCells || a.max_time != b.max_time ||
+        a.phase_update_interval != b.phase_update_interval || a.control != b.control ||
+        (a.nDead == -1) != (b.nDead == -1)) {
+      g_lastError = "pbSimCreateBatch: simulations of one batch must share nCells, grid, max_time, "
+                    "phase_update_interval, control and payload mode";
+      return PB_ERR_ARG;
+    }
+  }
+  if ((uint64_t)params[0].nCells * (uint64_t)nsims > 0xFFFFFFF0ull ||
+      (uint64_t)params[0].numCells * (uint64_t)nsims > 0xFFFFFFF0ull) {
+    g_lastError = "pbSimCreateBatch: batch too large for 32-bit slot / key indices";
     return PB_ERR_ARG;
   }
   int count = 0;
@@ -630,56 +723,70 @@ int pbSimCreate(pbSim **out, const SimParams *params, float wallHalf) {
     return PB_ERR_NO_DEVICE;
   }
   pbSim *S = new pbSim();
-  S->host = *params;
+  S->host = params[0];
   S->host.x1obs = S->host.x2obs = S->host.y1obs = S->host.y2obs = nullptr;
   S->host.x_cir_obs = S->host.y_cir_obs = S->host.r_cir_obs = nullptr;
-  pbFlattenParams(S->P, *params, wallHalf);
-  S->n = params->nCells;
+  S->nsims = (uint32_t)nsims;
+  S->n = params[0].nCells;
+  S->total = S->nsims * S->n;
+  S->hP.resize(nsims);
+  S->payload = params[0].nDead == -1;
+  S->fastOk = true;
+  for (int k = 0; k < nsims; k++) {
+    pbFlattenParams(S->hP[k], params[k], wallHalf);
+    S->fastOk = S->fastOk && pbFastMathAllowed(S->hP[k]);
+  }
   if (const char *v = getenv("PB_FORCE_VARIANT")) S->variant = atoi(v);  // A/B switch for benchmarking
-  const size_t n = S->n;
-#define PB_TRY_NEW(expr)            \
-  do {                              \
-    hipError_t e_ = (expr);         \
-    if (e_ != hipSuccess) {         \
+  const size_t n = S->n, total = S->total, G1 = (size_t)S->hP[0].numCells + 1;
+#define PB_TRY_NEW(expr)                                             \
+  do {                                                               \
+    hipError_t e_ = (expr);                                          \
+    if (e_ != hipSuccess) {                                          \
       g_lastError = std::string(hipGetErrorName(e_)) + " in " #expr; \
-      pbSimDestroy(S);              \
-      return PB_ERR_HIP;            \
-    }                               \
+      pbSimDestroy(S);                                               \
+      return PB_ERR_HIP;                                             \
+    }                                                                \
   } while (0)
   PB_TRY_NEW(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
   PB_TRY_NEW(hipEventCreate(&S->ev0));
   PB_TRY_NEW(hipEventCreate(&S->ev1));
+  PB_TRY_NEW(hipMalloc((void **)&S->dP, sizeof(PbDevParams) * nsims));
+  PB_TRY_NEW(hipMemcpyAsync(S->dP, S->hP.data(), sizeof(PbDevParams) * nsims, hipMemcpyHostToDevice, S->stream));
   for (int i = 0; i < 2; i++) {
-    PB_TRY_NEW(hipMalloc((void **)&S->pr[i], sizeof(float4) * n));
-    PB_TRY_NEW(hipMalloc((void **)&S->vel[i], sizeof(float2) * n));
-    PB_TRY_NEW(hipMalloc((void **)&S->phase[i], sizeof(float) * n));
-    PB_TRY_NEW(hipMalloc((void **)&S->dead[i], sizeof(int) * n));
-    PB_TRY_NEW(hipMalloc((void **)&S->absA[i], sizeof(float) * n));
-    PB_TRY_NEW(hipMalloc((void **)&S->absR[i], sizeof(float) * n));
-    PB_TRY_NEW(hipMalloc((void **)&S->orig[i], sizeof(uint32_t) * n));
-    PB_TRY_NEW(hipMalloc((void **)&S->keys[i], sizeof(uint32_t) * n));
-    PB_TRY_NEW(hipMalloc((void **)&S->vals[i], sizeof(uint32_t) * n));
-    PB_TRY_NEW(hipMemsetAsync(S->pr[i], 0, sizeof(float4) * n, S->stream));
-    PB_TRY_NEW(hipMemsetAsync(S->vel[i], 0, sizeof(float2) * n, S->stream));
-    PB_TRY_NEW(hipMemsetAsync(S->phase[i], 0, sizeof(float) * n, S->stream));
-    PB_TRY_NEW(hipMemsetAsync(S->dead[i], 0, sizeof(int) * n, S->stream));
-    PB_TRY_NEW(hipMemsetAsync(S->absA[i], 0, sizeof(float) * n, S->stream));
-    PB_TRY_NEW(hipMemsetAsync(S->absR[i], 0, sizeof(float) * n, S->stream));
+    PB_TRY_NEW(hipMalloc((void **)&S->pr[i], sizeof(float4) * total));
+    PB_TRY_NEW(hipMalloc((void **)&S->vel[i], sizeof(float2) * total));
+    PB_TRY_NEW(hipMalloc((void **)&S->phase[i], sizeof(float) * total));
+    PB_TRY_NEW(hipMalloc((void **)&S->dead[i], sizeof(int) * total));
+    PB_TRY_NEW(hipMalloc((void **)&S->absA[i], sizeof(float) * total));
+    PB_TRY_NEW(hipMalloc((void **)&S->absR[i], sizeof(float) * total));
+    PB_TRY_NEW(hipMalloc((void **)&S->orig[i], sizeof(uint32_t) * total));
+    PB_TRY_NEW(hipMalloc((void **)&S->keys[i], sizeof(uint32_t) * total));
+    PB_TRY_NEW(hipMalloc((void **)&S->vals[i], sizeof(uint32_t) * total));
+    PB_TRY_NEW(hipMemsetAsync(S->pr[i], 0, sizeof(float4) * total, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->vel[i], 0, sizeof(float2) * total, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->phase[i], 0, sizeof(float) * total, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->dead[i], 0, sizeof(int) * total, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->absA[i], 0, sizeof(float) * total, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->absR[i], 0, sizeof(float) * total, S->stream));
   }
-  PB_TRY_NEW(hipMalloc((void **)&S->cellS, sizeof(uint32_t) * ((size_t)S->P.numCells + 1)));
-  PB_TRY_NEW(hipMalloc((void **)&S->hist, sizeof(uint32_t) * pbSortHistEntries(S->n)));
-  PB_TRY_NEW(hipMalloc((void **)&S->slotOf, sizeof(uint32_t) * n));
-  PB_TRY_NEW(hipMalloc((void **)&S->dMin, sizeof(uint32_t)));
+  PB_TRY_NEW(hipMalloc((void **)&S->cellS, sizeof(uint32_t) * G1 * nsims));
+  PB_TRY_NEW(hipMalloc((void **)&S->hist, sizeof(uint32_t) * pbSortHistEntries(S->total)));
+  PB_TRY_NEW(hipMalloc((void **)&S->slotOf, sizeof(uint32_t) * total));
+  PB_TRY_NEW(hipMalloc((void **)&S->dMin, sizeof(uint32_t) * nsims));
+  PB_TRY_NEW(hipMalloc((void **)&S->dMinD, sizeof(float) * nsims));
   PB_TRY_NEW(hipMalloc((void **)&S->stage, 36 * n));
-  PB_TRY_NEW(hipMalloc((void **)&S->comPartial, sizeof(double2) * cdiv(S->n, TILE)));
-  PB_TRY_NEW(hipMalloc((void **)&S->comOut, sizeof(double2)));
-  PB_TRY_NEW(hipHostMalloc((void **)&S->hMin, sizeof(uint32_t)));
-  PB_TRY_NEW(hipHostMalloc((void **)&S->hCom, sizeof(double2)));
-  hipLaunchKernelGGL(k_iota, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->orig[0], S->n);
+  PB_TRY_NEW(hipMalloc((void **)&S->comPos, sizeof(float2) * total));
+  PB_TRY_NEW(hipMalloc((void **)&S->comPartial, sizeof(double2) * cdiv(S->n, TILE) * nsims));
+  PB_TRY_NEW(hipMalloc((void **)&S->comOut, sizeof(double2) * nsims));
+  PB_TRY_NEW(hipHostMalloc((void **)&S->hMin, sizeof(uint32_t) * nsims));
+  PB_TRY_NEW(hipHostMalloc((void **)&S->hMinD, sizeof(float) * nsims));
+  PB_TRY_NEW(hipHostMalloc((void **)&S->hCom, sizeof(double2) * nsims));
+  hipLaunchKernelGGL(k_iota, gridOf(S), dim3(TILE), 0, S->stream, S->orig[0], S->n);
   // attraction factor column and a defined radius for every slot
-  hipLaunchKernelGGL(k_set_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->P, S->orig[0], S->pr[0],
-                     S->vel[0], S->phase[0], S->dead[0], (const float2 *)nullptr, (const float2 *)nullptr,
-                     (const float *)nullptr, (const float *)nullptr, (const int *)nullptr, S->n);
+  for (uint32_t k = 0; k < S->nsims; k++)
+    hipLaunchKernelGGL(k_set_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->dP, k, S->orig[0], S->pr[0],
+                       S->vel[0], S->phase[0], S->dead[0], (const float2 *)nullptr, (const float2 *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, (const int *)nullptr, S->n);
   PB_TRY_NEW(hipGetLastError());
   PB_TRY_NEW(hipStreamSynchronize(S->stream));
 #undef PB_TRY_NEW
@@ -687,9 +794,20 @@ int pbSimCreate(pbSim **out, const SimParams *params, float wallHalf) {
   return PB_OK;
 }
 
-int pbSimSetState(pbSim *S, const float *pos, const float *vel, const float *rad, const float *phase,
-                  const int *dead) {
+int pbSimCreate(pbSim **out, const SimParams *params, float wallHalf) {
+  return pbSimCreateBatch(out, params, 1, wallHalf);
+}
+
+int pbSimBatchSize(pbSim *S, unsigned *nsims, unsigned *nbots) {
   if (!S) return PB_ERR_ARG;
+  if (nsims) *nsims = S->nsims;
+  if (nbots) *nbots = S->n;
+  return PB_OK;
+}
+
+int pbSimSetStateOf(pbSim *S, unsigned sim, const float *pos, const float *vel, const float *rad,
+                    const float *phase, const int *dead) {
+  if (!S || sim >= S->nsims) return PB_ERR_ARG;
   const size_t n = S->n;
   char *st = S->stage;
   float2 *dPos = (float2 *)st, *dVel = (float2 *)(st + 8 * n);
@@ -701,32 +819,25 @@ int pbSimSetState(pbSim *S, const float *pos, const float *vel, const float *rad
   if (phase) PB_TRY(hipMemcpyAsync(dPhase, phase, 4 * n, hipMemcpyHostToDevice, S->stream));
   if (dead) PB_TRY(hipMemcpyAsync(dDead, dead, 4 * n, hipMemcpyHostToDevice, S->stream));
   const int c = S->cur;
-  hipLaunchKernelGGL(k_set_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->P, S->orig[c], S->pr[c],
-                     S->vel[c], S->phase[c], S->dead[c], pos ? dPos : nullptr, vel ? dVel : nullptr,
+  hipLaunchKernelGGL(k_set_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->dP, sim, S->orig[c],
+                     S->pr[c], S->vel[c], S->phase[c], S->dead[c], pos ? dPos : nullptr, vel ? dVel : nullptr,
                      rad ? dRad : nullptr, phase ? dPhase : nullptr, dead ? dDead : nullptr, S->n);
   PB_TRY(hipGetLastError());
   PB_TRY(hipStreamSynchronize(S->stream));
   return PB_OK;
 }
 
-static int gatherToStage(pbSim *S) {
-  const size_t n = S->n;
-  char *st = S->stage;
-  const int c = S->cur;
-  hipLaunchKernelGGL(k_get_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->orig[c], S->pr[c], S->vel[c],
-                     S->phase[c], S->dead[c], S->absA[c], S->absR[c], (float2 *)st, (float2 *)(st + 8 * n),
-                     (float *)(st + 16 * n), (float *)(st + 20 * n), (int *)(st + 24 * n), (float *)(st + 28 * n),
-                     (float *)(st + 32 * n), S->n);
-  PB_TRY(hipGetLastError());
-  return PB_OK;
+int pbSimSetState(pbSim *S, const float *pos, const float *vel, const float *rad, const float *phase,
+                  const int *dead) {
+  return pbSimSetStateOf(S, 0, pos, vel, rad, phase, dead);
 }
 
-int pbSimGetState(pbSim *S, float *pos, float *vel, float *rad, float *phase, int *dead, float *absForce_a,
-                  float *absForce_r) {
-  if (!S) return PB_ERR_ARG;
+int pbSimGetStateOf(pbSim *S, unsigned sim, float *pos, float *vel, float *rad, float *phase, int *dead,
+                    float *absForce_a, float *absForce_r) {
+  if (!S || sim >= S->nsims) return PB_ERR_ARG;
   const size_t n = S->n;
   char *st = S->stage;
-  const int rc = gatherToStage(S);
+  const int rc = gatherToStage(S, sim);
   if (rc) return rc;
   if (pos) PB_TRY(hipMemcpyAsync(pos, st, 8 * n, hipMemcpyDeviceToHost, S->stream));
   if (vel) PB_TRY(hipMemcpyAsync(vel, st + 8 * n, 8 * n, hipMemcpyDeviceToHost, S->stream));
@@ -737,6 +848,11 @@ int pbSimGetState(pbSim *S, float *pos, float *vel, float *rad, float *phase, in
   if (absForce_r) PB_TRY(hipMemcpyAsync(absForce_r, st + 32 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
   PB_TRY(hipStreamSynchronize(S->stream));
   return PB_OK;
+}
+
+int pbSimGetState(pbSim *S, float *pos, float *vel, float *rad, float *phase, int *dead, float *absForce_a,
+                  float *absForce_r) {
+  return pbSimGetStateOf(S, 0, pos, vel, rad, phase, dead, absForce_a, absForce_r);
 }
 
 int pbSimSetTime(pbSim *S, float time) {
@@ -790,19 +906,30 @@ int pbSimSynchronize(pbSim *S) {
   return PB_OK;
 }
 
+int pbSimCentroids(pbSim *S, double *cxcy) {
+  if (!S || !cxcy) return PB_ERR_ARG;
+  const uint32_t nb = cdiv(S->n, TILE);
+  const int c = S->cur;
+  hipLaunchKernelGGL(k_com_scatter, gridOf(S), dim3(TILE), 0, S->stream, S->orig[c], S->pr[c], S->comPos, S->n);
+  hipLaunchKernelGGL(k_com_partial, dim3(nb, S->nsims), dim3(TILE), 0, S->stream, S->comPos, S->n, S->comPartial);
+  hipLaunchKernelGGL(k_com_final, dim3(S->nsims), dim3(64), 0, S->stream, S->comPartial, nb, S->n, S->comOut);
+  PB_TRY(hipGetLastError());
+  PB_TRY(hipMemcpyAsync(S->hCom, S->comOut, sizeof(double2) * S->nsims, hipMemcpyDeviceToHost, S->stream));
+  PB_TRY(hipStreamSynchronize(S->stream));
+  for (uint32_t k = 0; k < S->nsims; k++) {
+    cxcy[2 * k] = S->hCom[k].x;
+    cxcy[2 * k + 1] = S->hCom[k].y;
+  }
+  return PB_OK;
+}
+
 int pbSimCentroid(pbSim *S, double *cx, double *cy) {
   if (!S) return PB_ERR_ARG;
-  const int rc = gatherToStage(S);
+  std::vector<double> v(2 * (size_t)S->nsims);
+  const int rc = pbSimCentroids(S, v.data());
   if (rc) return rc;
-  const uint32_t nb = cdiv(S->n, TILE);
-  hipLaunchKernelGGL(k_com_partial, dim3(nb), dim3(TILE), 0, S->stream, (const float2 *)S->stage, S->n,
-                     S->comPartial);
-  hipLaunchKernelGGL(k_com_final, dim3(1), dim3(64), 0, S->stream, S->comPartial, nb, S->n, S->comOut);
-  PB_TRY(hipGetLastError());
-  PB_TRY(hipMemcpyAsync(S->hCom, S->comOut, sizeof(double2), hipMemcpyDeviceToHost, S->stream));
-  PB_TRY(hipStreamSynchronize(S->stream));
-  if (cx) *cx = S->hCom->x;
-  if (cy) *cy = S->hCom->y;
+  if (cx) *cx = v[0];
+  if (cy) *cy = v[1];
   return PB_OK;
 }
 

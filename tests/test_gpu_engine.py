@@ -283,3 +283,55 @@ def test_fast_math_disabled_for_out_of_domain_constants(pb, orc):
     osim.run(30)
     gsim.step(30)
     compare(osim, gsim, "tiny attraction")
+
+
+def test_ensemble_batch_matches_individual_oracles(pb, orc):
+    """pbSimCreateBatch: 12 simulations that differ in seed, light position, noise level, obstacles
+    and dead sets, stepped by the same launches, each bit-identical to its own oracle run -- through
+    the initial sort, two phase updates and a forced re-sort schedule."""
+    members, osims = [], []
+    keep = []
+    for k in range(12):
+        kw = dict(nCells=257, nDead=0, seed=1000 + k, light_x=-5.0 + 0.5 * k, light_y=0.3 * k,
+                  phase_std=0.6 if k % 3 else 0.0, max_time=1e9)
+        if k % 4 == 1:
+            kw.update(n_cir_obstacles=1, x_cir_obs=[4.0], y_cir_obs=[0.2], r_cir_obs=[0.4])
+        if k % 4 == 2:
+            kw.update(nobstacles=1, x1obs=[3.8], x2obs=[4.0], y1obs=[-1.0], y2obs=[1.0])
+        P = orc.default_params(**kw)
+        osim = orc.Sim(P)
+        if k % 5 == 0:
+            dead = np.zeros(257, np.int32)
+            dead[np.random.default_rng(k).choice(257, 40, replace=False)] = 1
+            osim.set("dead", dead)
+        sp, ka = simparams_from_orc(P)
+        members.append(sp)
+        keep.append(ka)
+        osims.append(osim)
+    ens = pb.Ensemble(members, keepalive=keep)
+    for k, osim in enumerate(osims):
+        ens.set_state_of(k, pos=osim.get("pos"), vel=osim.get("vel"), rad=osim.get("rad"),
+                         phase=osim.get("phase"), dead=osim.get("dead"))
+    step = 0
+    for upto in (1, 7, 1200, 1201, 2450):
+        for osim in osims:
+            osim.run(upto - step, sort_interval=7.0)
+        assert ens.step(upto - step, sort_interval=7.0) == upto - step
+        step = upto
+        for k, osim in enumerate(osims):
+            st = ens.get_state_of(k)
+            for key in STATE_KEYS:
+                assert_bit_equal(st[key], osim.get(key), f"member {k} step {upto}: {key}")
+    com = ens.centroids()
+    for k, osim in enumerate(osims):
+        ref = osim.get("pos").astype(np.float64).mean(0)
+        assert np.abs(com[k] - ref).max() < 1e-9
+    s = ens.stats()
+    assert s["steps"] == 2450 and s["phase_updates"] == 3 and s["resorts"] >= 3
+
+
+def test_ensemble_rejects_mismatched_members(pb, orc):
+    a, ka = simparams_from_orc(orc.default_params(nCells=100, nDead=0, seed=1))
+    b, kb = simparams_from_orc(orc.default_params(nCells=101, nDead=0, seed=2))
+    with pytest.raises(RuntimeError, match="must share"):
+        pb.Ensemble([a, b], keepalive=[ka, kb])
