@@ -40,7 +40,9 @@ class PbLibcRand {
 
 class Particlebot {
  public:
-  enum class Engine { Fused, Legacy };
+  /* HostOnly: no device objects at all -- placement, dead-bot draw and host mirrors only; used by
+   * the ensemble driver, which keeps every member's device state in one batched pbSim */
+  enum class Engine { Fused, Legacy, HostOnly };
 
   /* particlebot.h:17 -- engine taken from $PB_ENGINE ("legacy" or "fused", default fused);
    * wall half-extent 64 as in the reference */
@@ -95,6 +97,24 @@ class Particlebot {
   /* lattice pitch used by CONFIG_HEX placement; <= 0 selects the reference's 2*min_radius */
   void setHexSpacing(float pitch) { hexSpacing = pitch; }
   pbSim *engineHandle() { return sim; }
+  /* host mirrors in original bot order (valid after reset(); refreshed by getArray/dump) */
+  const float *hostPositions() const { return hPos; }
+  const float *hostVelocities() const { return hVel; }
+  const float *hostRadii() const { return hRad; }
+  const float *hostPhases() const { return hphase; }
+  const int *hostDead() const { return hDead; }
+  /* true when the step starting at the current time is the one that draws the dead bots
+   * (particlebot.cpp:178) */
+  bool deadDrawDue(float deltaTime) const {
+    return params.nDead > 0 && time >= params.time_to_dead && time < params.time_to_dead + deltaTime;
+  }
+  /* draws the dead set into the host mirror (and the engine, if any); returns the mirror */
+  const int *drawDeadBotsNow() {
+    drawDeadBots();
+    return hDead;
+  }
+  /* HostOnly engines follow an external clock */
+  void setHostTime(float t) { time = t; }
 
  protected:
   void _initialize();

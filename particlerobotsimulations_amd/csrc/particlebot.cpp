@@ -94,15 +94,17 @@ int PbLibcRand::next() {
 
 void Particlebot::setVerbosePlacement(bool on) { g_verbosePlacement = on; }
 
-Particlebot::Particlebot(SimParams simparams) : Particlebot(simparams, Engine::Fused, 64.0f) {}
+static Particlebot::Engine engineFromEnv() {
+  if (const char *e = getenv("PB_ENGINE"))
+    if (!strcmp(e, "legacy")) return Particlebot::Engine::Legacy;
+  return Particlebot::Engine::Fused;
+}
+
+Particlebot::Particlebot(SimParams simparams) : Particlebot(simparams, engineFromEnv(), 64.0f) {}
 
 Particlebot::Particlebot(SimParams simparams, Engine engine, float wall) : time(0), rng(simparams.seed) {
   params = simparams;
   engineKind = engine;
-  if (const char *e = getenv("PB_ENGINE")) {
-    if (!strcmp(e, "legacy")) engineKind = Engine::Legacy;
-    if (!strcmp(e, "fused")) engineKind = Engine::Fused;
-  }
   wallHalf = wall > 0.0f ? wall : 64.0f;
   particlebotConfigSize.x = particlebotConfigSize.y = 0;
   // The reference shallow-copies the obstacle pointers (particlebot.cpp:43); own them instead.
@@ -141,6 +143,7 @@ void Particlebot::_initialize() {
   hphase = hPhaseV.data();
   hDead = hDeadV.data();
 
+  if (engineKind == Engine::HostOnly) return;
   if (engineKind == Engine::Fused) {
     if (pbSimCreate(&sim, &params, wallHalf) != PB_OK) die("pbSimCreate");
     return;
@@ -224,7 +227,7 @@ void Particlebot::drawDeadBots() {
   }
   if (engineKind == Engine::Fused) {
     if (pbSimSetState(sim, nullptr, nullptr, nullptr, nullptr, hDead) != PB_OK) die("pbSimSetState(dead)");
-  } else {
+  } else if (engineKind == Engine::Legacy) {
     copyArrayToDevice(dDead, hDead, 0, (int)(params.nCells * sizeof(int)));
   }
 }
@@ -277,6 +280,10 @@ void Particlebot::update(float deltaTime, float sort_interval) {
 }
 
 int Particlebot::advance(float deltaTime, float sort_interval, int nsteps) {
+  if (engineKind == Engine::HostOnly) {
+    fprintf(stderr, "Particlebot: a HostOnly instance cannot step; its state lives in an ensemble batch\n");
+    exit(EXIT_FAILURE);
+  }
   int total = 0;
   const bool draws = params.nDead > 0;
   auto deadGate = [&](float t) { return t >= params.time_to_dead && t < params.time_to_dead + deltaTime; };
@@ -333,6 +340,7 @@ int Particlebot::stepsUntilHostEvent(float deltaTime, float dump_interval, int m
 
 void Particlebot::pullState(bool pos, bool vel, bool rad) {
   const uint n = params.nCells;
+  if (engineKind == Engine::HostOnly) return;
   if (engineKind == Engine::Fused) {
     if (pbSimGetState(sim, pos ? hPos : nullptr, vel ? hVel : nullptr, rad ? hRad : nullptr, nullptr, nullptr,
                       nullptr, nullptr) != PB_OK)
@@ -637,6 +645,7 @@ void Particlebot::reset() {
     }
     hphase[i] = 0;
   }
+  if (engineKind == Engine::HostOnly) return;
   if (engineKind == Engine::Fused) {
     if (pbSimSetState(sim, hPos, hVel, hRad, hphase, hDead) != PB_OK) die("pbSimSetState");
   } else {

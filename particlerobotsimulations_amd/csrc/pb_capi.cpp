@@ -1,9 +1,11 @@
 // pb_capi.cpp -- C wrappers around the C++ host side (class Particlebot + .cfg loader) so that
 // scripts and tests can drive it through ctypes.  Exported from libparticlebot_host.so.
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "particlebot.h"
 #include "pb_config.hpp"
@@ -247,6 +249,131 @@ void pbHostLibcRandDraws(unsigned seed, int n, int *out) {
   PbLibcRand g(seed);
   for (int i = 0; i < n; i++) out[i] = g.next();
 }
+
+// ---- ensembles: many independent simulations in one batched pbSim -----------------------------
+// Member k = the base .cfg + common overrides + its own overrides (typically "seed\n<k>").  The
+// host work of every member (random placement, dead-bot draw) runs in its own HostOnly Particlebot
+// with its own private libc-compatible stream; the device work of all members runs in ONE batched
+// pbSim, one launch per timestep.  Summaries (time, COMx, COMy, distance of COM to the light) are
+// taken whenever a dump row would be due.
+struct Ensemble {
+  std::vector<PbRunConfig *> cfgs;
+  std::vector<Particlebot *> bots;
+  pbSim *sim = nullptr;
+  ~Ensemble() {
+    if (sim) pbSimDestroy(sim);
+    for (auto *b : bots) delete b;
+    for (auto *c : cfgs) delete c;
+  }
+};
+
+void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
+                       int nmembers) {
+  if (nmembers < 1) return nullptr;
+  Ensemble *e = new Ensemble();
+  std::vector<SimParams> params;
+  for (int k = 0; k < nmembers; k++) {
+    PbRunConfig *cfg = new PbRunConfig();
+    cfg->params.seed = 0;
+    e->cfgs.push_back(cfg);
+    if (cfg_path && !cfg->loadFile(cfg_path)) {
+      delete e;
+      return nullptr;
+    }
+    applyOverrides(*cfg, common_overrides);
+    if (member_overrides) applyOverrides(*cfg, member_overrides[k]);
+    cfg->derive();
+    Particlebot *bot = new Particlebot(cfg->params, Particlebot::Engine::HostOnly, cfg->wallHalf());
+    bot->setHexSpacing(cfg->hex_spacing);
+    bot->reset();
+    e->bots.push_back(bot);
+    params.push_back(bot->getParams());
+  }
+  if (pbSimCreateBatch(&e->sim, params.data(), nmembers, e->cfgs[0]->wallHalf()) != PB_OK) {
+    fprintf(stderr, "pbEnsembleCreate: %s\n", pbGetLastErrorString());
+    delete e;
+    return nullptr;
+  }
+  for (int k = 0; k < nmembers; k++) {
+    Particlebot *b = e->bots[k];
+    if (pbSimSetStateOf(e->sim, (unsigned)k, b->hostPositions(), b->hostVelocities(), b->hostRadii(),
+                        b->hostPhases(), b->hostDead()) != PB_OK) {
+      fprintf(stderr, "pbEnsembleCreate: %s\n", pbGetLastErrorString());
+      delete e;
+      return nullptr;
+    }
+  }
+  return e;
+}
+
+void pbEnsembleDestroy(void *ev) { delete (Ensemble *)ev; }
+
+// Runs every member to max_time.  out: [nmembers][max_rows][4] floats (time, COMx, COMy, distance
+// of the COM to the light); *rows receives the number of rows written per member (the same for
+// all).  Returns the number of timesteps executed, or -1 on error.
+long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
+  Ensemble *e = (Ensemble *)ev;
+  const int m = (int)e->bots.size();
+  const PbRunConfig &c0 = *e->cfgs[0];
+  const float dt = c0.timestep, di = c0.dump_interval;
+  std::vector<double> com(2 * (size_t)m);
+  long steps = 0;
+  int nrows = 0;
+  float t = 0.0f;
+  if (pbSimGetTime(e->sim, &t) != PB_OK) return -1;
+  for (;;) {
+    if (!(t - di * floorf(t / di) > 0.01f) && nrows < max_rows) {  // the dump test, particlebot.cpp:309
+      if (pbSimCentroids(e->sim, com.data()) != PB_OK) return -1;
+      for (int k = 0; k < m; k++) {
+        const SimParams &p = e->bots[k]->getParams();
+        float *row = out + ((size_t)k * max_rows + nrows) * 4;
+        const double dx = com[2 * k] - p.light_x, dy = com[2 * k + 1] - p.light_y;
+        row[0] = t;
+        row[1] = (float)com[2 * k];
+        row[2] = (float)com[2 * k + 1];
+        row[3] = (float)sqrt(dx * dx + dy * dy);
+      }
+      nrows++;
+    }
+    if (t > c0.params.max_time) break;
+    // host events at this step: dead-bot draws
+    for (int k = 0; k < m; k++) {
+      Particlebot *b = e->bots[k];
+      b->setHostTime(t);
+      if (b->deadDrawDue(dt)) {
+        if (pbSimSetStateOf(e->sim, (unsigned)k, nullptr, nullptr, nullptr, nullptr, b->drawDeadBotsNow()) != PB_OK)
+          return -1;
+      }
+    }
+    // run up to (not past) the next dump row or dead-bot draw of any member
+    int run = 1;
+    float tt = t + dt;
+    for (;;) {
+      bool stop = !(tt - di * floorf(tt / di) > 0.01f) || tt > c0.params.max_time || run >= (1 << 20);
+      for (int k = 0; k < m && !stop; k++) {
+        e->bots[k]->setHostTime(tt);
+        stop = e->bots[k]->deadDrawDue(dt);
+      }
+      if (stop) break;
+      tt = tt + dt;
+      run++;
+    }
+    int done = 0;
+    if (pbSimStep(e->sim, dt, c0.sort_interval, run, &done) != PB_OK) return -1;
+    steps += done;
+    if (pbSimGetTime(e->sim, &t) != PB_OK) return -1;
+    if (done == 0) break;
+  }
+  if (rows) *rows = nrows;
+  return steps;
+}
+
+int pbEnsembleGetState(void *ev, int member, float *pos, float *vel, float *rad) {
+  Ensemble *e = (Ensemble *)ev;
+  return pbSimGetStateOf(e->sim, (unsigned)member, pos, vel, rad, nullptr, nullptr, nullptr, nullptr);
+}
+
+unsigned pbEnsembleNumBots(void *ev) { return ((Ensemble *)ev)->bots[0]->getParams().nCells; }
 
 unsigned pbHostNumBots(void *hv) { return ((HostSim *)hv)->bot->getParams().nCells; }
 

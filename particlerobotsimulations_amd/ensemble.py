@@ -1,0 +1,153 @@
+"""Ensembles of independent simulations (Monte-Carlo seeds, parameter sweeps) sharded over the GPUs
+of a node: SURVEY.md 8(e).
+
+  member k  ->  rank k mod world_size           (equal counts, no data-path collective)
+  per rank  ->  ONE batched pbSim holding all of the rank's members (one launch per timestep)
+  exchange  ->  per-member summary rows (time, COMx, COMy, distance to light), gathered once at the
+                end with all_gather (RCCL over xGMI on GPUs; gloo in the CPU tests)
+
+Run as a script under torch.distributed.run for N > 1:
+  python -m particlerobotsimulations_amd.ensemble examples/example_obstacle.cfg --members 256 \
+         --seed0 1000 --set max_time 1200
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+
+
+def shard(n_members, rank, world):
+    """Indices of the members rank `rank` runs (round-robin: equal counts +-1)."""
+    return list(range(rank, n_members, world))
+
+
+def member_overrides(k, seed0=0, sweep=None):
+    """Override text of member k: its seed, plus one sweep value if `sweep` = (key, values)."""
+    text = f"seed\n{seed0 + k}"
+    if sweep is not None:
+        key, values = sweep
+        text += f"\n{key}\n{values[k % len(values)]}"
+    return text
+
+
+def run_local(cfg_path, overrides_per_member, common=None, max_rows=4096, final_state=False):
+    """Run the given members (a list of override strings) as one batch on the current GPU.
+    Returns (rows[m, r, 4] float32, steps), plus a list of per-member dicts (pos, vel, rad at the
+    end of the run) when final_state is set."""
+    from . import host
+    L = host.lib()
+    L.pbEnsembleCreate.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
+    L.pbEnsembleCreate.restype = C.c_void_p
+    L.pbEnsembleDestroy.argtypes = [C.c_void_p]
+    L.pbEnsembleRun.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.pbEnsembleRun.restype = C.c_long
+    m = len(overrides_per_member)
+    if m == 0:
+        return np.zeros((0, 0, 4), np.float32), 0
+    arr = (C.c_char_p * m)(*[o.encode() for o in overrides_per_member])
+    common_b = "\n".join(f"{k}\n{v}" for k, v in (common or {}).items()).encode() or None
+    h = L.pbEnsembleCreate(os.fsencode(cfg_path), common_b, arr, m)
+    if not h:
+        raise RuntimeError("pbEnsembleCreate failed")
+    try:
+        out = np.zeros((m, max_rows, 4), np.float32)
+        rows = C.c_int()
+        steps = L.pbEnsembleRun(h, out.ctypes.data_as(C.c_void_p), max_rows, C.byref(rows))
+        if steps < 0:
+            raise RuntimeError("pbEnsembleRun failed")
+        if final_state:
+            L.pbEnsembleNumBots.argtypes = [C.c_void_p]
+            L.pbEnsembleNumBots.restype = C.c_uint
+            L.pbEnsembleGetState.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            n = L.pbEnsembleNumBots(h)
+            states = []
+            for k in range(m):
+                st = {"pos": np.empty((n, 2), np.float32), "vel": np.empty((n, 2), np.float32),
+                      "rad": np.empty(n, np.float32)}
+                if L.pbEnsembleGetState(h, k, *[st[x].ctypes.data_as(C.c_void_p) for x in ("pos", "vel", "rad")]):
+                    raise RuntimeError("pbEnsembleGetState failed")
+                states.append(st)
+            return out[:, :rows.value].copy(), int(steps), states
+        return out[:, :rows.value].copy(), int(steps)
+    finally:
+        L.pbEnsembleDestroy(h)
+
+
+def gather_summaries(local_rows, n_members, rank, world, dist=None, device="cpu"):
+    """All ranks' summary rows assembled in member order: [n_members, rows, 4].  The one collective
+    of an ensemble run (tens of KB: latency-bound, nowhere near a link's bandwidth)."""
+    if world == 1 or dist is None:
+        return local_rows
+    import torch
+    per = (n_members + world - 1) // world
+    rows = local_rows.shape[1] if local_rows.size else 0
+    r = torch.tensor([rows], dtype=torch.int64, device=device)
+    dist.all_reduce(r, op=dist.ReduceOp.MAX)
+    rows = int(r.item())
+    pad = np.full((per, rows, 4), np.nan, np.float32)
+    pad[:local_rows.shape[0], :local_rows.shape[1]] = local_rows
+    mine = torch.from_numpy(pad).to(device)
+    allv = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    out = np.full((n_members, rows, 4), np.nan, np.float32)
+    for rk in range(world):
+        ids = shard(n_members, rk, world)
+        out[ids] = allv[rk].cpu().numpy()[:len(ids)]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cfg")
+    ap.add_argument("--members", type=int, default=32)
+    ap.add_argument("--seed0", type=int, default=1000)
+    ap.add_argument("--set", nargs=2, action="append", default=[], metavar=("NAME", "VALUE"))
+    ap.add_argument("--sweep", nargs="+", default=None, metavar="KEY V1 V2 ...")
+    ap.add_argument("--out", default=None, help="write the gathered summaries (.npy) on rank 0")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    device = "cpu"
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        device = f"cuda:{local_rank}"
+        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+    sweep = (args.sweep[0], args.sweep[1:]) if args.sweep else None
+    ids = shard(args.members, rank, world)
+    t0 = time.perf_counter()
+    rows, steps = run_local(args.cfg, [member_overrides(k, args.seed0, sweep) for k in ids], dict(args.set))
+    wall = time.perf_counter() - t0
+    allrows = gather_summaries(rows, args.members, rank, world, dist, device)
+    if world > 1:
+        import torch
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if rank == 0:
+        from . import host
+        n = host.load_config(args.cfg, **dict(args.set)).nCells
+        last = allrows[:, -1]
+        first = allrows[:, 0]
+        toward = first[:, 3] - last[:, 3]  # decrease of the COM's distance to the light
+        print(json.dumps({
+            "cfg": os.path.basename(args.cfg), "members": args.members, "n_gpus": world, "bots_per_member": int(n),
+            "steps_per_member": steps, "rows_per_member": int(allrows.shape[1]), "wall_s": wall,
+            "sims_per_s": args.members / wall, "particle_steps_per_s": args.members * n * steps / wall,
+            "progress_toward_light_mean": float(np.nanmean(toward)), "progress_toward_light_std": float(np.nanstd(toward)),
+        }))
+        if args.out:
+            np.save(args.out, allrows)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""CPU tests of the multi-GPU ensemble layer: member -> rank sharding and the one
+collective (all_gather of per-member summary rows), exercised with world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def test_shard_is_a_partition():
+    from particlerobotsimulations_amd.ensemble import shard
+    for n, w in ((256, 8), (1024, 8), (10, 4), (3, 8), (0, 2)):
+        parts = [shard(n, r, w) for r in range(w)]
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_member_overrides_text():
+    from particlerobotsimulations_amd.ensemble import member_overrides
+    assert member_overrides(3, seed0=1000) == "seed\n1003"
+    assert member_overrides(5, 10, ("nDead", ["0", "10", "20"])) == "seed\n15\nnDead\n20"
+
+
+def _fake_rows(member, rows):
+    """what a rank would have computed for this member"""
+    t = np.arange(rows, dtype=np.float32)
+    return np.stack([t, member + 0.25 * t, -member - 0.5 * t, 100.0 - member - t], -1)
+
+
+def _worker(rank, world, port, n_members, rows, q):
+    import torch.distributed as dist
+    from particlerobotsimulations_amd.ensemble import gather_summaries, shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    ids = shard(n_members, rank, world)
+    local = np.stack([_fake_rows(k, rows) for k in ids]) if ids else np.zeros((0, rows, 4), np.float32)
+    out = gather_summaries(local.astype(np.float32), n_members, rank, world, dist, "cpu")
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_members", [7, 8])
+def test_gather_world_size_2_gloo(n_members):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    rows = 5
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_members, rows, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([_fake_rows(k, rows) for k in range(n_members)]).astype(np.float32)
+    for r in range(2):
+        assert got[r].shape == want.shape
+        assert np.array_equal(got[r], want)
+
+
+def test_gather_single_rank_is_identity():
+    from particlerobotsimulations_amd.ensemble import gather_summaries
+    x = np.random.default_rng(0).random((3, 4, 4)).astype(np.float32)
+    assert gather_summaries(x, 3, 0, 1) is x

@@ -152,3 +152,35 @@ def test_headless_runner_binary(orc, tmp_path):
     ref = str(tmp_path / "oracle.csv")
     oracle_csv(orc, EX("example_obstacle.cfg"), ref, **{k: v for k, v in over.items() if k != "csv_filename"})
     assert open(ref, "rb").read() == out.read_bytes()
+
+
+def test_ensemble_members_equal_individual_runs(host, tmp_path):
+    """a batched ensemble (one pbSim, one launch per timestep for all members) gives
+    every member exactly the state a stand-alone run with that seed gives: placement, dead-bot draw
+    (example_dead_cells: 20 of 100, drawn at t = 0 from each member's own stream), phase noise."""
+    import ctypes as C
+    from particlerobotsimulations_amd import ensemble
+    cfg = EX("example_dead_cells.cfg")
+    common = {"max_time": "1.55", "dump_interval": "0.5"}
+    seeds = [6666, 1, 2, 3, 4, 5, 77, 123456]
+    rows, steps, states = ensemble.run_local(cfg, [f"seed\n{s}" for s in seeds], common, final_state=True)
+    assert rows.shape[0] == len(seeds) and rows.shape[2] == 4 and steps >= 155
+    assert np.allclose(rows[:, 0, 0], 0.0) and np.all(np.diff(rows[0, :, 0]) > 0)
+    # the same members one at a time through class Particlebot
+    for k, s in enumerate(seeds):
+        solo = host.HostSim(cfg, seed=str(s), **common)
+        coms = []
+        while True:
+            if solo.steps_until_dump(1) >= 1 and abs(solo.time - rows[k, len(coms), 0]) < 1e-7:
+                coms.append(solo.get("pos").astype(np.float64).mean(0))
+            if solo.finished or len(coms) == rows.shape[1]:
+                break
+            solo.advance(1)
+        assert len(coms) == rows.shape[1]
+        assert np.abs(np.array(coms) - rows[k, :, 1:3]).max() < 1e-6, (k, coms, rows[k])
+        while not solo.finished:
+            solo.advance(1)
+        for key in ("pos", "vel", "rad"):
+            assert_bit_equal(states[k][key], solo.get(key), f"member {k} final {key}")
+    # different seeds really are different blobs
+    assert len({tuple(np.round(r[-1, 1:3], 5)) for r in rows}) == len(seeds)
