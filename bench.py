@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--pitch", type=float, default=LATTICE_PITCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-survey-literal", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,8 +174,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         # torch first: its bundled HIP runtime must be the one instance in the process
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -181,8 +187,8 @@ def main():
 
     import particlerobotsimulations_amd as pb
 
-    if world == 1:
-        pb.legacy.cudaInit(0, None)  # N > 1: torch.cuda.set_device above already chose this rank's GPU
+    if dist is None:
+        pb.legacy.cudaInit(0, None)  # otherwise torch.cuda.set_device above already chose this rank's GPU
 
     n = args.bots
     sim = make_sim(pb, n, args.pitch, seed=1 + rank)

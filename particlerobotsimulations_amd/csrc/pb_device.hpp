@@ -384,8 +384,14 @@ PB_DEV PbPairTerm pbPairEval(const PbDevParams &P, bool live, float ax, float ay
 // K neighbours evaluated side by side in the same basic blocks (one shared contact branch, one
 // shared rare-sqrt branch), so the scheduler can interleave K independent dependency chains.
 // Each term equals pbPairEval's for that neighbour.
+// the three contact constants, copied out of the parameter block once per kernel (the block lives
+// in device memory; left to itself hipcc re-reads it inside the neighbour loop)
+struct PbContactK {
+  float spring, damping, shear;
+};
+
 template <bool FAST, int K, class VelFetch>
-PB_DEV void pbPairEvalK(const PbDevParams &P, const bool (&live)[K], float ax, float ay, float avx, float avy,
+PB_DEV void pbPairEvalK(const PbContactK &P, const bool (&live)[K], float ax, float ay, float avx, float avy,
                         float ra, const float (&bx)[K], const float (&by)[K], const float (&rb)[K],
                         const float (&attraction)[K], const float (&slope)[K], VelFetch velB,
                         PbPairTerm (&out)[K]) {

@@ -48,7 +48,10 @@ thread_local std::string g_lastError;
     }                                                                                                \
   } while (0)
 
-constexpr int TILE = 256;
+#ifndef PB_TILE
+#define PB_TILE 256
+#endif
+constexpr int TILE = PB_TILE;
 #ifndef PB_NB
 #define PB_NB 1
 #endif
@@ -114,6 +117,8 @@ __global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ 
   F.fr = 0.0f * absR[s];  // impl.cuh:688
 
   const float slope0 = pbBandSlope(P.attraction);
+  const float attraction0 = P.attraction;
+  const PbContactK CK{P.spring, P.damping, P.shear};
   const uint32_t GX = P.gridX;
   const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
   const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;  // cells before the x-wrap
@@ -147,13 +152,13 @@ __global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ 
               by[k] = q[k].y;
               rb[k] = q[k].z;
               // payload factors ride in q.w / att1 (impl.cuh:629-633, 640-649)
-              A[k] = PAYLOAD ? P.attraction * q[k].w * att1 : P.attraction;
+              A[k] = PAYLOAD ? attraction0 * q[k].w * att1 : attraction0;
               K[k] = PAYLOAD ? pbBandSlope(A[k]) : slope0;
             }
 #pragma unroll
             for (int k = 0; k < NB; k++) q[k] = prIn[j + NB + k < hi ? j + NB + k : s];
             PbPairTerm t[NB];
-            pbPairEvalK<FAST, NB>(P, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
+            pbPairEvalK<FAST, NB>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
                                   [&](int k) { return velIn[idx[k]]; }, t);
 #pragma unroll
             for (int k = 0; k < NB; k++) pbPairAdd(live[k], t[k], F);
