@@ -265,7 +265,15 @@ __global__ __launch_bounds__(TILE) void k_min_dist2(const PbDevParams *__restric
     const uint32_t o = __shfl_xor(bits, d, 64);
     bits = o < bits ? o : bits;
   }
-  if ((threadIdx.x & 63u) == 0u) atomicMin(&outBits[blockIdx.y], bits);
+  __shared__ uint32_t waveMin[TILE / 64];
+  if ((threadIdx.x & 63u) == 0u) waveMin[threadIdx.x >> 6] = bits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t m = waveMin[0];
+#pragma unroll
+    for (int w = 1; w < TILE / 64; w++) m = waveMin[w] < m ? waveMin[w] : m;
+    atomicMin(&outBits[blockIdx.y], m);  // one per workgroup
+  }
 }
 
 // updatePhase (impl.cuh:264-290) + add_normal_noise (impl.cuh:43-51) in slot order

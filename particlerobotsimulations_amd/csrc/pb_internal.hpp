@@ -13,7 +13,11 @@ constexpr int PB_SORT_TILE = PB_SORT_THREADS * PB_SORT_ITEMS;
 
 static inline uint32_t pbSortBlocks(uint32_t n) { return (n + PB_SORT_TILE - 1) / PB_SORT_TILE; }
 // number of uint32 entries the histogram workspace needs for n pairs
-static inline size_t pbSortHistEntries(uint32_t n) { return (size_t)256 * (pbSortBlocks(n) ? pbSortBlocks(n) : 1); }
+// (the 256 x nblocks digit table, plus one sum per 2048-entry chunk of it for the scan)
+static inline size_t pbSortHistEntries(uint32_t n) {
+  const size_t table = (size_t)256 * (pbSortBlocks(n) ? pbSortBlocks(n) : 1);
+  return table + (table + 2047) / 2048 + 1;
+}
 
 // Sorts n pairs by the low `bits` bits of the key; equal keys keep their input order (this is what
 // thrust::sort_by_key gives the reference, particlebot_cuda.cu:377-382).  Buffers ping-pong; the

@@ -6,7 +6,8 @@
 //
 // One pass = three kernels over tiles of PB_SORT_TILE pairs:
 //   histogram : per-workgroup 256-bin digit histogram in LDS            -> hist[digit][block]
-//   scan      : exclusive prefix sum over that digit-major table        -> global base per (digit, block)
+//   scan      : exclusive prefix sum over that digit-major table (3 small launches: chunk sums,
+//               scan of the sums, rescan of each chunk)                  -> global base per (digit, block)
 //   scatter   : each wave walks its 64-pair chunks in order; lanes holding the same digit find each
 //               other with 8 wave ballots, rank themselves with a popcount of the lower lanes, and
 //               a per-wave running counter in LDS carries the order from chunk to chunk and (after
@@ -35,15 +36,17 @@ __global__ __launch_bounds__(PB_SORT_THREADS) void k_sort_hist(const uint32_t *_
   hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = bins[threadIdx.x];
 }
 
-// Exclusive scan of `m` uint32 entries in place, one workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t *__restrict__ a, uint32_t m) {
-  __shared__ uint32_t waveSum[16];
-  const uint32_t per = (m + 1023u) / 1024u;
-  const uint32_t lo = threadIdx.x * per;
-  const uint32_t hi = lo + per < m ? lo + per : m;
-  uint32_t sum = 0;
-  for (uint32_t i = lo; i < hi; i++) sum += a[i];
-  // inclusive scan of the 1024 thread sums: wave shuffles, then the 16 wave totals
+// Exclusive scan of the digit-major histogram table (m entries) in three small launches: per-chunk
+// sums, a one-workgroup scan of the chunk sums, then each chunk rescanned onto its base.  Inside a
+// workgroup a thread owns SCAN_PER consecutive entries; thread sums are scanned with wave shuffles
+// and the 4 wave totals go through LDS.
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER = 8;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_PER;
+
+// exclusive prefix of `sum` over the workgroup; *total receives the workgroup's total
+__device__ __forceinline__ uint32_t blockExclusive(uint32_t sum, uint32_t *total) {
+  __shared__ uint32_t waveSum[SCAN_THREADS / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t inc = sum;
 #pragma unroll
@@ -53,13 +56,57 @@ __global__ __launch_bounds__(1024) void k_sort_scan(uint32_t *__restrict__ a, ui
   }
   if (lane == 63) waveSum[wave] = inc;
   __syncthreads();
-  uint32_t waveBase = 0;
-  for (int w = 0; w < wave; w++) waveBase += waveSum[w];
-  uint32_t run = waveBase + inc - sum;  // exclusive prefix of this thread's chunk
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t v = a[i];
-    a[i] = run;
-    run += v;
+  uint32_t base = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; w++) {
+    if (w < wave) base += waveSum[w];
+    all += waveSum[w];
+  }
+  if (total) *total = all;
+  __syncthreads();
+  return base + inc - sum;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_chunk_sums(const uint32_t *__restrict__ a, uint32_t m,
+                                                                  uint32_t *__restrict__ chunkSum) {
+  const uint32_t lo = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_PER;
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; k++)
+    if (lo + k < m) sum += a[lo + k];
+  uint32_t total;
+  (void)blockExclusive(sum, &total);
+  if (threadIdx.x == 0) chunkSum[blockIdx.x] = total;
+}
+
+// one workgroup: exclusive scan of the nchunks chunk sums, in place
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(uint32_t *__restrict__ chunkSum, uint32_t nchunks) {
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nchunks; base += SCAN_THREADS) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nchunks ? chunkSum[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = blockExclusive(v, &total);
+    if (i < nchunks) chunkSum[i] = carry + ex;
+    carry += total;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t *__restrict__ a, uint32_t m,
+                                                             const uint32_t *__restrict__ chunkBase) {
+  const uint32_t lo = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_PER;
+  uint32_t v[SCAN_PER];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; k++) {
+    v[k] = lo + k < m ? a[lo + k] : 0u;
+    sum += v[k];
+  }
+  uint32_t run = chunkBase[blockIdx.x] + blockExclusive(sum, nullptr);
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; k++) {
+    if (lo + k < m) a[lo + k] = run;
+    run += v[k];
   }
 }
 
@@ -134,7 +181,11 @@ int pbRadixSortPairs(uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_
   int where = 0;
   for (int shift = 0; shift < bits; shift += 8) {
     hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(PB_SORT_THREADS), 0, stream, kin, hist, n, shift, nblocks);
-    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, stream, hist, 256u * nblocks);
+    const uint32_t m = 256u * nblocks, nchunks = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    uint32_t *chunkSum = hist + m;  // the workspace has room for the chunk sums behind the table
+    hipLaunchKernelGGL(k_scan_chunk_sums, dim3(nchunks), dim3(SCAN_THREADS), 0, stream, hist, m, chunkSum);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, stream, chunkSum, nchunks);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nchunks), dim3(SCAN_THREADS), 0, stream, hist, m, chunkSum);
     hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(PB_SORT_THREADS), 0, stream, kin, vin, kout, vout,
                        hist, n, shift, nblocks);
     uint32_t *t = kin;
