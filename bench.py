@@ -156,6 +156,16 @@ def survey_literal(pb, n, steps, warmup):
                     "(see the LATTICE_PITCH comment in bench.py)"}
 
 
+def profiled_traffic():
+    """HBM bytes per k_force launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/latest_traffic.json, written by tools/profile.sh); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as fh:
+            return json.load(fh)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +241,7 @@ def main():
         # the simulation's own stream around the timed region
         avg_launch_s = (dev_ms * 1e-3) / max(launches, 1)
         achieved = ALG_BYTES_PER_PARTICLE_STEP * n / avg_launch_s / 1e9
+        tr = profiled_traffic() if n == 1_000_000 else None
         out = {
             "metric": "particle-steps/sec at 10^6 bots; achieved HBM GB/s vs peak; 1/2/4/8-GPU ensemble",
             "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
@@ -242,7 +253,10 @@ def main():
                        "bots_per_gpu": n, "dt": 0.01, "sort_interval": 180.0,
                        "parallelism": "single arena" if world == 1 else f"{world} independent arenas, one per GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                         "traffic_source": (f"profiles/latest_traffic.json ({tr['profile']}): {tr['method']}"
+                                            if tr else None),
                          "kernel": "k_force<FUSE> (forces of step n + radius/integration of step n+1)",
                          "launches": launches, "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * n,

@@ -4,7 +4,7 @@
 # usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-run}; shift || true
-ARGS=${@:---steps 200 --warmup 20 --no-cpu-baseline}
+ARGS=${@:---steps 400 --warmup 100 --no-cpu-baseline --no-survey-literal}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -18,5 +18,5 @@ run pmc_sq --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_
 run pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
 run pmc_fetch --pmc FETCH_SIZE
 run pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
+python3 tools/summarize_profile.py "$OUT" "$OUT/traffic.json" > "$OUT/summary.md" 2>"$OUT/summarize.err"
 cat "$OUT/summary.md"

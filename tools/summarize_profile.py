@@ -47,6 +47,7 @@ def pmc(root, sub):
 
 def main():
     root = sys.argv[1]
+    traffic_json = sys.argv[2] if len(sys.argv) > 2 else None
     agg, meta = kernel_trace(root)
     total = sum(sum(v) for v in agg.values()) or 1
     print(f"# rocprofv3 summary: {os.path.basename(root)}\n")
@@ -85,6 +86,16 @@ def main():
         if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
             fetch = 2.0 * d.get("FETCH_SIZE", 0.0) * 1024  # gfx950: reports half of wide coalesced reads
             write = d.get("WRITE_SIZE", 0.0) * 1024
+            if traffic_json and k.startswith("k_force<true"):
+                import json
+                with open(traffic_json, "w") as fh:
+                    json.dump({"kernel": k, "profile": os.path.basename(root), "fetch_bytes_per_launch": fetch,
+                               "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
+                               "avg_launch_us_profiled": avg_ns / 1e3,
+                               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
+                                         "`python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline "
+                                         "--no-survey-literal`; FETCH_SIZE x2 (gfx950 wide-read correction) "
+                                         "x1024, WRITE_SIZE x1024 (MI355X_MICROARCH.md, HBM section)"}, fh)
             print(f"- derived: HBM-side traffic per launch = read {fetch/1e6:.1f} MB (FETCH_SIZE x2 x1024) + "
                   f"write {write/1e6:.1f} MB = {(fetch+write)/1e6:.1f} MB; at {avg_ns/1e3:.1f} us/launch = "
                   f"{(fetch+write)/avg_ns:.1f} GB/s")
