@@ -185,6 +185,11 @@ int pbSimSetResortEveryStep(pbSim *sim, int on);
  * with the fast exact sqrt/division forms (default; falls back to 1 when the simulation's
  * constants are outside their proven domain).  All variants give bit-identical results. */
 int pbSimSetForceVariant(pbSim *sim, int variant);
+/* Shape of the force kernel's neighbour loop: 1 = throughput form (one bot per lane, one neighbour
+ * per trip); 4 = four neighbours evaluated side by side (ILP, for batches too small to fill the
+ * chip); 8 = eight lanes per bot (tiny batches); 0 = automatic (default).  Results do not depend
+ * on it. */
+int pbSimSetLanesPerBot(pbSim *sim, int lanes);
 
 /* On-device check that the fast exact forms equal the compiler's IEEE sqrtf and division: every
  * float in the sqrt domain, and div_samples sampled (numerator, numerator, denominator) triples

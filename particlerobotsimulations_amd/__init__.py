@@ -224,6 +224,9 @@ class Sim:
     def set_force_variant(self, variant):
         _capi.check(_capi.lib().pbSimSetForceVariant(self._h, int(variant)))
 
+    def set_lanes_per_bot(self, lanes):
+        _capi.check(_capi.lib().pbSimSetLanesPerBot(self._h, int(lanes)))
+
     def set_resort_every_step(self, on):
         _capi.check(_capi.lib().pbSimSetResortEveryStep(self._h, 1 if on else 0))
 

@@ -119,6 +119,7 @@ SYMBOLS = {
     "pbSimGetStats": (_I, [_VP, C.POINTER(pbSimStats)]),
     "pbSimSetResortEveryStep": (_I, [_VP, _I]),
     "pbSimSetForceVariant": (_I, [_VP, _I]),
+    "pbSimSetLanesPerBot": (_I, [_VP, _I]),
     "pbSelfTest": (_I, [C.c_ulonglong] + [C.POINTER(C.c_ulonglong)] * 4),
 }
 

@@ -52,10 +52,9 @@ thread_local std::string g_lastError;
 #define PB_TILE 256
 #endif
 constexpr int TILE = PB_TILE;
-#ifndef PB_NB
-#define PB_NB 1
-#endif
-constexpr int NB = PB_NB;  // neighbours evaluated side by side per loop trip
+// NB (template parameter of k_force): neighbours evaluated side by side per loop trip.  1 is the
+// throughput form (8 waves/SIMD, the VALU pipe is the limit); 4 is used for batches too small to
+// fill the chip, where a lone wave's dependent-issue latency is the limit and ILP pays.
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
@@ -84,7 +83,34 @@ __global__ __launch_bounds__(TILE) void k_state(const PbDevParams *__restrict__ 
 // pair evaluation (pbPairFlat) instead of the reference-shaped branches (pbPair).
 // FASTOK: the simulation passed pbFastMathAllowed, so waves whose lanes all pass
 // pbLaneFastMathOk may use the exact fast sqrt/division forms.
-template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK>
+// Ordered sum over the L lanes of a group: term e of the group is broadcast to all its lanes with
+// ds_swizzle in bit-mask mode (source lane = (lane & and_mask) | e, inside each 32-lane half; the
+// pattern must be an immediate, hence the compile-time recursion) and added, e = 0 .. L-1.
+template <int L, int E>
+struct GroupSum {
+  static __device__ __forceinline__ void add(const PbPairTerm &t, int flags, PbForce &F) {
+    constexpr int PAT = (E << 5) | (0x1F & ~(L - 1));
+    PbPairTerm u;
+    u.tx = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(t.tx), PAT));
+    u.ty = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(t.ty), PAT));
+    u.mag = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(t.mag), PAT));
+    const int fl = __builtin_amdgcn_ds_swizzle(flags, PAT);
+    u.contact = (fl & 2) != 0;
+    pbPairAdd((fl & 1) != 0, u, F);
+    GroupSum<L, E + 1>::add(t, flags, F);
+  }
+};
+template <int L>
+struct GroupSum<L, L> {
+  static __device__ __forceinline__ void add(const PbPairTerm &, int, PbForce &) {}
+};
+
+// L: lanes per bot.  L == 1 is the throughput form (one bot per lane).  L > 1 (small batches that
+// cannot fill the chip) gives each bot L adjacent lanes: they evaluate L candidates of the bot's
+// flattened neighbour list at a time, then every lane of the group adds the L terms in list order
+// (ds_swizzle broadcasts inside the group), so the sums -- and their order -- are those of L == 1.
+// The serial chain per bot shrinks ~L/2-fold at ~2x the total VALU work.
+template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB>
 __global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ params,
                                                 const float4 *__restrict__ prIn, const float2 *__restrict__ velIn,
                                                 float4 *__restrict__ prOut, float2 *__restrict__ velOut,
@@ -98,7 +124,8 @@ __global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ 
   // (round-robin dispatch); give each XCD one contiguous eighth of the tiles (gridDim.x = 8*perXcd).
   // perXcd == 0: plain order (small simulations, a handful of tiles each).
   const uint32_t tile = perXcd ? (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3) : blockIdx.x;
-  const uint32_t l = tile * TILE + threadIdx.x;
+  const uint32_t l = tile * (TILE / L) + threadIdx.x / L;  // all L lanes of a group share the bot
+  const uint32_t sub = threadIdx.x % L;
   if (l >= n) return;
   const uint32_t s = blockIdx.y * n + l;  // global slot; the cell table holds global slots too
   const uint32_t *__restrict__ cellS = cellSAll + (size_t)blockIdx.y * (P.numCells + 1u);
@@ -123,27 +150,103 @@ __global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ 
   const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
   const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;  // cells before the x-wrap
   const int nseg = first < 5u ? 2 : 1;
-  auto sweep = [&](auto fastTag) {
+  // ---- L > 1: flattened candidate list, L candidates per trip, ordered group sum --------------
+  auto sweepML = [&](auto fastTag) {
     constexpr bool FAST = decltype(fastTag)::value;
+    constexpr int SEG = 10;  // 5 grid rows x up to 2 ranges (x-wrap)
+    uint32_t off[SEG], cum[SEG + 1];
+    cum[0] = 0;
+#pragma unroll
     for (int dy = -2; dy <= 2; dy++) {
       const uint32_t row = ((uint32_t)(gy + dy) & (P.gridY - 1u)) * GX;
-      for (int sg = 0; sg < nseg; sg++) {
-        const uint32_t c0 = sg == 0 ? mx0 : 0u;
-        const uint32_t c1 = sg == 0 ? mx0 + first : 5u - first;
-        const uint32_t lo = cellS[row + c0];
-        const uint32_t hi = cellS[row + c1];
+#pragma unroll
+      for (int sg = 0; sg < 2; sg++) {
+        const int si = (dy + 2) * 2 + sg;
+        uint32_t lo = 0, hi = 0;
+        if (sg < nseg) {
+          const uint32_t c0 = sg == 0 ? mx0 : 0u;
+          const uint32_t c1 = sg == 0 ? mx0 + first : 5u - first;
+          lo = cellS[row + c0];
+          hi = cellS[row + c1];
+        }
+        off[si] = lo - cum[si];  // slot of list position k inside this range: k + off
+        cum[si + 1] = cum[si] + (hi - lo);
+      }
+    }
+    const uint32_t m = cum[SEG];
+    auto slotOf = [&](uint32_t k) {
+      uint32_t o = off[0];
+#pragma unroll
+      for (int r = 1; r < SEG; r++) o = k >= cum[r] ? off[r] : o;
+      return k < m ? k + o : s;  // beyond the list: the bot's own slot, never accumulated
+    };
+    uint32_t jn = slotOf(sub);
+    float4 qn = prIn[jn];
+    for (uint32_t base = 0; base < m; base += L) {
+      const uint32_t j = jn;
+      const float4 q = qn;
+      jn = slotOf(base + L + sub);
+      qn = prIn[jn];
+      const bool live[1] = {j != s};
+      const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
+      const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
+      const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
+      PbPairTerm t[1];
+      pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
+                           [&](int) { return velIn[j]; }, t);
+      const int flags = (live[0] ? 1 : 0) | (t[0].contact ? 2 : 0);
+      // every lane of the group adds the group's L terms in list order
+      GroupSum<L, 0>::add(t[0], flags, F);
+    }
+  };
+  if (L > 1) {
+    if (FASTOK && __all(pbLaneFastMathOk(me.x, me.y))) sweepML(std::true_type{});
+    else sweepML(std::false_type{});
+  }
+
+  auto sweep = [&](auto fastTag) {
+    constexpr bool FAST = decltype(fastTag)::value;
+    // all ten cell-table reads are issued together (one memory latency, not five)
+    uint32_t segLo[10], segHi[10];
+#pragma unroll
+    for (int dy = -2; dy <= 2; dy++) {
+      const uint32_t row = ((uint32_t)(gy + dy) & (P.gridY - 1u)) * GX;
+#pragma unroll
+      for (int sg = 0; sg < 2; sg++) {
+        const int si = (dy + 2) * 2 + sg;
+        segLo[si] = 0;
+        segHi[si] = 0;
+        if (sg < nseg) {
+          segLo[si] = cellS[row + (sg == 0 ? mx0 : 0u)];
+          segHi[si] = cellS[row + (sg == 0 ? mx0 + first : 5u - first)];
+        }
+      }
+    }
+#pragma unroll
+    for (int si = 0; si < 10; si++) {
+      if ((si & 1) && nseg == 1) continue;  // second range of a row only exists at the x-wrap
+      const uint32_t lo = segLo[si], hi = segHi[si];
+      {
         if (FLAT) {
           // NB neighbours per trip, evaluated side by side (independent dependency chains for the
           // scheduler to interleave) and then summed in slot order.  The next trip's posrad loads
           // are already in flight (software pipeline).  Out-of-range slots alias the lane's own
-          // slot s, which is never accumulated.
+          // slot s, which is never accumulated.  With NB > 1 (latency form) the neighbours'
+          // velocities travel with their posrad instead of being fetched inside the contact branch.
+          constexpr bool PREVEL = NB > 1;
           float4 q[NB];
+          float2 vq[NB];
 #pragma unroll
-          for (int k = 0; k < NB; k++) q[k] = prIn[lo + k < hi ? lo + k : s];
+          for (int k = 0; k < NB; k++) {
+            const uint32_t i0 = lo + k < hi ? lo + k : s;
+            q[k] = prIn[i0];
+            if (PREVEL) vq[k] = velIn[i0];
+          }
           for (uint32_t j = lo; j < hi; j += NB) {
             bool live[NB];
             uint32_t idx[NB];
             float bx[NB], by[NB], rb[NB], A[NB], K[NB];
+            float2 vb[NB];
 #pragma unroll
             for (int k = 0; k < NB; k++) {
               idx[k] = j + k < hi ? j + k : s;
@@ -151,15 +254,20 @@ __global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ 
               bx[k] = q[k].x;
               by[k] = q[k].y;
               rb[k] = q[k].z;
+              if (PREVEL) vb[k] = vq[k];
               // payload factors ride in q.w / att1 (impl.cuh:629-633, 640-649)
               A[k] = PAYLOAD ? attraction0 * q[k].w * att1 : attraction0;
               K[k] = PAYLOAD ? pbBandSlope(A[k]) : slope0;
             }
 #pragma unroll
-            for (int k = 0; k < NB; k++) q[k] = prIn[j + NB + k < hi ? j + NB + k : s];
+            for (int k = 0; k < NB; k++) {
+              const uint32_t i1 = j + NB + k < hi ? j + NB + k : s;
+              q[k] = prIn[i1];
+              if (PREVEL) vq[k] = velIn[i1];
+            }
             PbPairTerm t[NB];
             pbPairEvalK<FAST, NB>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
-                                  [&](int k) { return velIn[idx[k]]; }, t);
+                                  [&](int k) { return PREVEL ? vb[k] : velIn[idx[k]]; }, t);
 #pragma unroll
             for (int k = 0; k < NB; k++) pbPairAdd(live[k], t[k], F);
           }
@@ -174,8 +282,10 @@ __global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ 
     }
   };
   // wave-uniform choice: the fast exact forms need every lane's coordinates away from zero
-  if (FLAT && FASTOK && __all(pbLaneFastMathOk(me.x, me.y))) sweep(std::true_type{});
-  else sweep(std::false_type{});
+  if (L == 1) {
+    if (FLAT && FASTOK && __all(pbLaneFastMathOk(me.x, me.y))) sweep(std::true_type{});
+    else sweep(std::false_type{});
+  }
   pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
   pbFrictionAndKick(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
 
@@ -184,10 +294,12 @@ __global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ 
     if (doRadiusNext) out.z = pbActuate(P, me.z, phase[s], dead[s], F.fa, F.fr, timeNext, dt);
     pbIntegrate(P, out.x, out.y, v.x, v.y, out.z, dt);
   }
-  prOut[s] = out;
-  velOut[s] = v;
-  absA[s] = F.fa;
-  absR[s] = F.fr;
+  if (sub == 0) {  // the L lanes of a group hold identical results
+    prOut[s] = out;
+    velOut[s] = v;
+    absA[s] = F.fa;
+    absR[s] = F.fr;
+  }
 }
 
 // re-sort step 1: hash in ORIGINAL order (calcHashD, impl.cuh:446-465) + inverse permutation.
@@ -500,6 +612,7 @@ struct pbSim {
   bool resortEveryStep = false;
   bool payload = false, fastOk = false;
   int variant = 2;  // force kernel: 0 reference-shaped branches, 1 branch-free, 2 (default) + fast exact math
+  int lanesPerBot = 0;  // latency form: 0 automatic; 1 throughput form; 4 ILP form (4 neighbours side by side); 8 eight lanes per bot
   pbSimStats stats{};
 };
 
@@ -512,13 +625,13 @@ inline bool gate(float t, float interval, float dt) {
 
 inline dim3 gridOf(const pbSim *S) { return dim3(cdiv(S->n, TILE), S->nsims); }
 
-template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK>
+template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB>
 void launchForceT(pbSim *S, int c, int o, float dt, float tNext, int doRadiusNext) {
-  const uint32_t tiles = cdiv(S->n, TILE);
+  const uint32_t tiles = cdiv(S->n, TILE / L);
   // XCD-aware order only pays when a simulation spans many tiles
-  const uint32_t perXcd = tiles >= 64u ? cdiv(tiles, 8u) : 0u;
+  const uint32_t perXcd = (L == 1 && tiles >= 64u) ? cdiv(tiles, 8u) : 0u;
   const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
-  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK>), grid, dim3(TILE), 0, S->stream, S->dP, S->pr[c],
+  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK, L, NB>), grid, dim3(TILE), 0, S->stream, S->dP, S->pr[c],
                      S->vel[c], S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c],
                      S->cellS, S->n, dt, tNext, doRadiusNext, perXcd);
 }
@@ -527,8 +640,21 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
   const bool payload = S->payload;
   // variant 0: reference-shaped branches; 1: branch-free; 2 (default): branch-free + fast exact math
   const int kind = S->variant == 0 ? 0 : (S->variant == 1 || !S->fastOk) ? 1 : 2;
-#define PB_CASE(F, PL, K, FL, FA) \
-  if (fuse == F && payload == PL && kind == K) return launchForceT<F, PL, FL, FA>(S, c, o, dt, tNext, doRadiusNext);
+  // Small batches (under ~1 wave per SIMD) are bound by one wave's serial neighbour loop, not by
+  // VALU throughput.  Two latency forms: NB = 4 neighbours side by side (ILP), and for tiny batches
+  // additionally 8 lanes per bot.  Only the branch-free kernels have them.  form: 0 throughput,
+  // 1 ILP, 2 multi-lane.
+  int form = 0;
+  if (kind != 0) {
+    if (S->lanesPerBot == 8 || (S->lanesPerBot == 0 && S->total <= 4096u)) form = 2;
+    else if (S->lanesPerBot == 4 || (S->lanesPerBot == 0 && S->total <= 131072u)) form = 1;
+  }
+#define PB_CASE(F, PL, K, FL, FA)                                                                        \
+  if (fuse == F && payload == PL && kind == K) {                                                         \
+    if (FL && form == 2) return launchForceT<F, PL, FL, FA, (FL ? 8 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
+    if (FL && form == 1) return launchForceT<F, PL, FL, FA, 1, (FL ? 4 : 1)>(S, c, o, dt, tNext, doRadiusNext); \
+    return launchForceT<F, PL, FL, FA, 1, 1>(S, c, o, dt, tNext, doRadiusNext);                            \
+  }
   PB_CASE(true, true, 0, false, false)
   PB_CASE(true, true, 1, true, false)
   PB_CASE(true, true, 2, true, true)
@@ -749,7 +875,8 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     pbFlattenParams(S->hP[k], params[k], wallHalf);
     S->fastOk = S->fastOk && pbFastMathAllowed(S->hP[k]);
   }
-  if (const char *v = getenv("PB_FORCE_VARIANT")) S->variant = atoi(v);  // A/B switch for benchmarking
+  if (const char *v = getenv("PB_FORCE_VARIANT")) S->variant = atoi(v);  // A/B switches for benchmarking
+  if (const char *v = getenv("PB_LANES_PER_BOT")) S->lanesPerBot = atoi(v);
   const size_t n = S->n, total = S->total, G1 = (size_t)S->hP[0].numCells + 1;
 #define PB_TRY_NEW(expr)                                             \
   do {                                                               \
@@ -955,6 +1082,12 @@ int pbSimGetStats(pbSim *S, pbSimStats *stats) {
 int pbSimSetForceVariant(pbSim *S, int variant) {
   if (!S || variant < 0 || variant > 2) return PB_ERR_ARG;
   S->variant = variant;
+  return PB_OK;
+}
+
+int pbSimSetLanesPerBot(pbSim *S, int lanes) {
+  if (!S || !(lanes == 0 || lanes == 1 || lanes == 4 || lanes == 8)) return PB_ERR_ARG;
+  S->lanesPerBot = lanes;
   return PB_OK;
 }
 

@@ -335,3 +335,33 @@ def test_ensemble_rejects_mismatched_members(pb, orc):
     b, kb = simparams_from_orc(orc.default_params(nCells=101, nDead=0, seed=2))
     with pytest.raises(RuntimeError, match="must share"):
         pb.Ensemble([a, b], keepalive=[ka, kb])
+
+
+@pytest.mark.parametrize("lanes", [1, 4, 8])
+@pytest.mark.parametrize("case", ["payload_obstacles", "wrap_walls"])
+def test_lanes_per_bot_forms_match_oracle(pb, orc, lanes, case):
+    """The throughput form (one bot per lane, one neighbour per trip) and the two latency forms of
+    the force kernel (4 neighbours side by side; 8 lanes per bot) add the same terms in the same
+    order: all bit-identical to the oracle, also at the grid's x-wrap where a stencil row splits
+    into two slot ranges."""
+    rng = np.random.default_rng(5)
+    if case == "payload_obstacles":
+        P = orc.default_params(nCells=777, nDead=-1, seed=21, phase_std=0.6, max_time=1e9, light_x=-5.0, light_y=0.0,
+                               attractionFactor=0.3, massFactor=1.7, n_cir_obstacles=1, x_cir_obs=[3.9],
+                               y_cir_obs=[0.2], r_cir_obs=[0.5], nobstacles=1, x1obs=[5.5], x2obs=[5.7],
+                               y1obs=[-0.5], y2obs=[0.5])
+        osim, gsim = make_pair(pb, orc, P)
+    else:
+        P = orc.default_params(nCells=1500, nDead=0, seed=9, phase_std=0.0, max_time=1e9, light_x=80.0, light_y=80.0)
+        osim, gsim = make_pair(pb, orc, P)
+        pos, vel, rad = jittered_blob(1500, 0.16, rng, center=(57.0, 61.0))
+        vel += np.float32(0.3)
+        osim.set("pos", pos), osim.set("vel", vel), osim.set("rad", rad)
+        gsim.set_state(pos=pos, vel=vel, rad=rad)
+    gsim.set_lanes_per_bot(lanes)
+    step = 0
+    for k in (1, 3, 40, 1203):
+        osim.run(k - step)
+        gsim.step(k - step)
+        step = k
+        compare(osim, gsim, f"{case} lanes={lanes} step {k}")
