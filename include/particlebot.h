@@ -32,6 +32,9 @@ class PbLibcRand {
   void reseed(unsigned seed);
   int next(); /* == rand(): 31 bits */
   static constexpr int kMax = 2147483647; /* RAND_MAX */
+  /* full generator state (for checkpoints): 34 table words + the two cursors */
+  void getState(int out[36]) const;
+  void setState(const int in[36]);
 
  private:
   int r[34];
@@ -113,6 +116,12 @@ class Particlebot {
     drawDeadBots();
     return hDead;
   }
+  /* Exact checkpoint (extension; fused engine): time, phase-noise draw counter, the private
+   * generator's state, every state array INCLUDING phase / dead / absForce_a / absForce_r, and the
+   * stale slot layout (which the reference's CSV resume loses): a run resumed from it continues
+   * bit-identically.  Both return false on I/O or format errors. */
+  bool saveCheckpoint(FILE *fp);
+  bool loadCheckpoint(FILE *fp);
   /* HostOnly engines follow an external clock */
   void setHostTime(float t) { time = t; }
 

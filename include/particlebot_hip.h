@@ -146,6 +146,15 @@ int pbSimSetStateOf(pbSim *sim, unsigned member, const float *pos, const float *
                     const float *phase, const int *dead);
 int pbSimGetStateOf(pbSim *sim, unsigned member, float *pos, float *vel, float *rad, float *phase, int *dead,
                     float *absForce_a, float *absForce_r);
+/* Exact checkpoints.  Between re-sorts the cell lists are STALE by design (the reference re-hashes
+ * only every sort_interval), so a bit-identical resume needs, besides the state arrays, the layout:
+ * orig[i] = original index of the bot in slot i, keys[i] = the cell hash slot i was filed under at
+ * the last sort (ascending).  *sorted is 0 if the simulation has not been sorted yet.  After
+ * pbSimSetLayoutOf for every member, restore the state with pbSimSetStateOf + pbSimSetForcesOf,
+ * pbSimSetTime and pbSimSetPhaseDraws. */
+int pbSimGetLayoutOf(pbSim *sim, unsigned member, unsigned *orig, unsigned *keys, int *sorted);
+int pbSimSetLayoutOf(pbSim *sim, unsigned member, const unsigned *orig, const unsigned *keys);
+int pbSimSetForcesOf(pbSim *sim, unsigned member, const float *absForce_a, const float *absForce_r);
 /* centre of mass of every member: cxcy[2*k], cxcy[2*k+1]; reduced on the device in a fixed order */
 int pbSimCentroids(pbSim *sim, double *cxcy);
 

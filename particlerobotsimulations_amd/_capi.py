@@ -106,6 +106,9 @@ SYMBOLS = {
     "pbSimSetStateOf": (_I, [_VP, _U, _VP, _VP, _VP, _VP, _VP]),
     "pbSimGetStateOf": (_I, [_VP, _U] + [_VP] * 7),
     "pbSimCentroids": (_I, [_VP, C.POINTER(C.c_double)]),
+    "pbSimGetLayoutOf": (_I, [_VP, _U, _VP, _VP, C.POINTER(_I)]),
+    "pbSimSetLayoutOf": (_I, [_VP, _U, _VP, _VP]),
+    "pbSimSetForcesOf": (_I, [_VP, _U, _VP, _VP]),
     "pbSimSetState": (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "pbSimGetState": (_I, [_VP] * 8),
     "pbSimSetTime": (_I, [_VP, _F]),

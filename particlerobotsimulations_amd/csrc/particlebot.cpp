@@ -92,6 +92,18 @@ int PbLibcRand::next() {
   return out;
 }
 
+void PbLibcRand::getState(int out[36]) const {
+  for (int i = 0; i < 34; i++) out[i] = r[i];
+  out[34] = f;
+  out[35] = b;
+}
+
+void PbLibcRand::setState(const int in[36]) {
+  for (int i = 0; i < 34; i++) r[i] = in[i];
+  f = in[34];
+  b = in[35];
+}
+
 void Particlebot::setVerbosePlacement(bool on) { g_verbosePlacement = on; }
 
 static Particlebot::Engine engineFromEnv() {
@@ -655,4 +667,57 @@ void Particlebot::reset() {
     setArray(POSITION, hPos, 0, n);
     setArray(VELOCITY, hVel, 0, n);
   }
+}
+
+// ---- exact checkpoints (extension) -----------------------------------------
+
+namespace {
+const char kCkptMagic[8] = {'P', 'B', 'C', 'K', 'P', 'T', '1', 0};
+template <class T>
+bool putv(FILE *fp, const T *p, size_t count) { return fwrite(p, sizeof(T), count, fp) == count; }
+template <class T>
+bool getv(FILE *fp, T *p, size_t count) { return fread(p, sizeof(T), count, fp) == count; }
+}  // namespace
+
+bool Particlebot::saveCheckpoint(FILE *fp) {
+  if (engineKind != Engine::Fused || !fp) return false;
+  const uint n = params.nCells;
+  std::vector<float> absA(n), absR(n);
+  std::vector<unsigned> orig(n), keys(n);
+  int sorted = 0;
+  unsigned draws = 0;
+  if (pbSimGetState(sim, hPos, hVel, hRad, hphase, hDead, absA.data(), absR.data()) != PB_OK) return false;
+  if (pbSimGetLayoutOf(sim, 0, orig.data(), keys.data(), &sorted) != PB_OK) return false;
+  if (pbSimGetPhaseDraws(sim, &draws) != PB_OK) return false;
+  int rs[36];
+  rng.getState(rs);
+  return putv(fp, kCkptMagic, 8) && putv(fp, &n, 1) && putv(fp, &time, 1) && putv(fp, &draws, 1) &&
+         putv(fp, &sorted, 1) && putv(fp, rs, 36) && putv(fp, hPos, 2 * (size_t)n) && putv(fp, hVel, 2 * (size_t)n) &&
+         putv(fp, hRad, n) && putv(fp, hphase, n) && putv(fp, hDead, n) && putv(fp, absA.data(), n) &&
+         putv(fp, absR.data(), n) && putv(fp, orig.data(), n) && putv(fp, keys.data(), n);
+}
+
+bool Particlebot::loadCheckpoint(FILE *fp) {
+  if (engineKind != Engine::Fused || !fp) return false;
+  const uint n = params.nCells;
+  char magic[8];
+  uint fileN = 0;
+  float t = 0;
+  unsigned draws = 0;
+  int sorted = 0, rs[36];
+  if (!getv(fp, magic, 8) || memcmp(magic, kCkptMagic, 8) != 0 || !getv(fp, &fileN, 1) || fileN != n) return false;
+  std::vector<float> absA(n), absR(n);
+  std::vector<unsigned> orig(n), keys(n);
+  if (!(getv(fp, &t, 1) && getv(fp, &draws, 1) && getv(fp, &sorted, 1) && getv(fp, rs, 36) &&
+        getv(fp, hPos, 2 * (size_t)n) && getv(fp, hVel, 2 * (size_t)n) && getv(fp, hRad, n) && getv(fp, hphase, n) &&
+        getv(fp, hDead, n) && getv(fp, absA.data(), n) && getv(fp, absR.data(), n) && getv(fp, orig.data(), n) &&
+        getv(fp, keys.data(), n)))
+    return false;
+  if (sorted && pbSimSetLayoutOf(sim, 0, orig.data(), keys.data()) != PB_OK) return false;
+  if (pbSimSetState(sim, hPos, hVel, hRad, hphase, hDead) != PB_OK) return false;
+  if (pbSimSetForcesOf(sim, 0, absA.data(), absR.data()) != PB_OK) return false;
+  if (pbSimSetPhaseDraws(sim, draws) != PB_OK) return false;
+  rng.setState(rs);
+  setTime(t);
+  return true;
 }

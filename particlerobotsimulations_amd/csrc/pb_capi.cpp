@@ -223,6 +223,22 @@ int pbHostLoadFromFile(void *hv, const char *path) {
   return 0;
 }
 
+int pbHostSaveCheckpoint(void *hv, const char *path) {
+  FILE *fp = fopen(path, "wb");
+  if (!fp) return -1;
+  const bool ok = ((HostSim *)hv)->bot->saveCheckpoint(fp);
+  fclose(fp);
+  return ok ? 0 : -2;
+}
+
+int pbHostLoadCheckpoint(void *hv, const char *path) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return -1;
+  const bool ok = ((HostSim *)hv)->bot->loadCheckpoint(fp);
+  fclose(fp);
+  return ok ? 0 : -2;
+}
+
 // which: 0 POSITION (2n floats) 1 VELOCITY (2n) 2 RADII (n) 3 PHASE (n) 5 DEAD (n ints)
 int pbHostGetArray(void *hv, int which, void *out) {
   HostSim *h = (HostSim *)hv;

@@ -456,6 +456,19 @@ __global__ __launch_bounds__(TILE) void k_get_state(uint32_t sim, const uint32_t
   outAbsR[o] = absR[s];
 }
 
+// absForce_a / absForce_r of ONE simulation, original order -> slot order (checkpoint restore)
+__global__ __launch_bounds__(TILE) void k_set_forces(uint32_t sim, const uint32_t *__restrict__ orig,
+                                                     float *__restrict__ absA, float *__restrict__ absR,
+                                                     const float *__restrict__ inA, const float *__restrict__ inR,
+                                                     uint32_t n) {
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t s = sim * n + l;
+  const uint32_t o = orig[s];
+  absA[s] = inA[o];
+  absR[s] = inR[o];
+}
+
 __global__ __launch_bounds__(TILE) void k_iota(uint32_t *__restrict__ a, uint32_t n) {
   const uint32_t l = blockIdx.x * TILE + threadIdx.x;
   if (l < n) a[blockIdx.y * n + l] = l;
@@ -597,6 +610,9 @@ struct pbSim {
 
   uint32_t *cellS = nullptr;  // nsims x (numCells+1), global slot indices
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *slotOf = nullptr;
+  uint32_t *sortedKeys = nullptr;  // keys[0] or keys[1]: composite keys of the slots, as of the last sort
+  std::vector<uint32_t> layoutOrig, layoutKeys;  // host staging of pbSimSetLayoutOf
+  std::vector<char> layoutGiven;
   uint32_t *dMin = nullptr;  // nsims
   float *dMinD = nullptr;    // nsims
   uint32_t *hMin = nullptr;  // pinned, nsims
@@ -688,6 +704,7 @@ int resort(pbSim *S) {
   PB_TRY(hipGetLastError());
   S->cur = o;
   S->haveCells = true;
+  S->sortedKeys = S->keys[where];
   S->stats.resorts++;
   return PB_OK;
 }
@@ -993,6 +1010,76 @@ int pbSimGetStateOf(pbSim *S, unsigned sim, float *pos, float *vel, float *rad, 
 int pbSimGetState(pbSim *S, float *pos, float *vel, float *rad, float *phase, int *dead, float *absForce_a,
                   float *absForce_r) {
   return pbSimGetStateOf(S, 0, pos, vel, rad, phase, dead, absForce_a, absForce_r);
+}
+
+/* ---- layout (which bot sits in which slot, and under which stale cell) for exact checkpoints ---- */
+int pbSimGetLayoutOf(pbSim *S, unsigned sim, unsigned *orig, unsigned *keys, int *sorted) {
+  if (!S || sim >= S->nsims) return PB_ERR_ARG;
+  const size_t n = S->n;
+  if (sorted) *sorted = S->haveCells ? 1 : 0;
+  PB_TRY(hipStreamSynchronize(S->stream));
+  if (orig) PB_TRY(hipMemcpy(orig, S->orig[S->cur] + (size_t)sim * n, 4 * n, hipMemcpyDeviceToHost));
+  if (keys) {
+    if (S->haveCells) {
+      PB_TRY(hipMemcpy(keys, S->sortedKeys + (size_t)sim * n, 4 * n, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n; i++) keys[i] -= sim * S->hP[0].numCells;  // strip the member number
+    } else {
+      memset(keys, 0, 4 * n);
+    }
+  }
+  return PB_OK;
+}
+
+int pbSimSetLayoutOf(pbSim *S, unsigned sim, const unsigned *orig, const unsigned *keys) {
+  if (!S || sim >= S->nsims || !orig || !keys) return PB_ERR_ARG;
+  const size_t n = S->n;
+  if (S->layoutOrig.empty()) {
+    S->layoutOrig.assign((size_t)S->total, 0);
+    S->layoutKeys.assign((size_t)S->total, 0);
+    S->layoutGiven.assign(S->nsims, 0);
+  }
+  std::vector<char> seen(n, 0);
+  uint32_t prev = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (orig[i] >= n || seen[orig[i]] || keys[i] >= S->hP[0].numCells || keys[i] < prev) {
+      g_lastError = "pbSimSetLayoutOf: orig must be a permutation and keys ascending cell hashes";
+      return PB_ERR_ARG;
+    }
+    seen[orig[i]] = 1;
+    prev = keys[i];
+    S->layoutOrig[sim * n + i] = orig[i];
+    S->layoutKeys[sim * n + i] = sim * S->hP[0].numCells + keys[i];
+  }
+  S->layoutGiven[sim] = 1;
+  for (char g : S->layoutGiven)
+    if (!g) return PB_OK;  // wait for the other members
+  // every member provided: install the slot order and rebuild the dense cell tables
+  PB_TRY(hipMemcpyAsync(S->orig[S->cur], S->layoutOrig.data(), 4 * (size_t)S->total, hipMemcpyHostToDevice, S->stream));
+  PB_TRY(hipMemcpyAsync(S->keys[0], S->layoutKeys.data(), 4 * (size_t)S->total, hipMemcpyHostToDevice, S->stream));
+  hipLaunchKernelGGL(k_cell_scan, dim3(cdiv(S->hP[0].numCells + 1u, TILE), S->nsims), dim3(TILE), 0, S->stream,
+                     S->keys[0], S->total, S->cellS, S->hP[0].numCells);
+  PB_TRY(hipGetLastError());
+  PB_TRY(hipStreamSynchronize(S->stream));
+  S->sortedKeys = S->keys[0];
+  S->haveCells = true;
+  S->layoutOrig.clear();
+  S->layoutKeys.clear();
+  S->layoutGiven.clear();
+  return PB_OK;
+}
+
+int pbSimSetForcesOf(pbSim *S, unsigned sim, const float *absForce_a, const float *absForce_r) {
+  if (!S || sim >= S->nsims || !absForce_a || !absForce_r) return PB_ERR_ARG;
+  const size_t n = S->n;
+  float *dA = (float *)(S->stage + 28 * n), *dR = (float *)(S->stage + 32 * n);
+  PB_TRY(hipMemcpyAsync(dA, absForce_a, 4 * n, hipMemcpyHostToDevice, S->stream));
+  PB_TRY(hipMemcpyAsync(dR, absForce_r, 4 * n, hipMemcpyHostToDevice, S->stream));
+  const int c = S->cur;
+  hipLaunchKernelGGL(k_set_forces, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, sim, S->orig[c], S->absA[c],
+                     S->absR[c], dA, dR, S->n);
+  PB_TRY(hipGetLastError());
+  PB_TRY(hipStreamSynchronize(S->stream));
+  return PB_OK;
 }
 
 int pbSimSetTime(pbSim *S, float time) {

@@ -75,6 +75,10 @@ def lib():
     L.pbHostDump.restype = C.c_int
     L.pbHostLoadFromFile.argtypes = [C.c_void_p, C.c_char_p]
     L.pbHostLoadFromFile.restype = C.c_int
+    L.pbHostSaveCheckpoint.argtypes = [C.c_void_p, C.c_char_p]
+    L.pbHostSaveCheckpoint.restype = C.c_int
+    L.pbHostLoadCheckpoint.argtypes = [C.c_void_p, C.c_char_p]
+    L.pbHostLoadCheckpoint.restype = C.c_int
     L.pbHostGetArray.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.pbHostGetArray.restype = C.c_int
     L.pbHostSetArray.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
@@ -155,6 +159,16 @@ class HostSim:
     def load_from_file(self, path):
         if lib().pbHostLoadFromFile(self._h, os.fsencode(path)) != 0:
             raise OSError(path)
+
+    def save_checkpoint(self, path):
+        rc = lib().pbHostSaveCheckpoint(self._h, os.fsencode(path))
+        if rc != 0:
+            raise OSError(f"saveCheckpoint({path}) failed ({rc})")
+
+    def load_checkpoint(self, path):
+        rc = lib().pbHostLoadCheckpoint(self._h, os.fsencode(path))
+        if rc != 0:
+            raise OSError(f"loadCheckpoint({path}) failed ({rc})")
 
     def get(self, name):
         which, dt, w = {"pos": (0, np.float32, 2), "vel": (1, np.float32, 2), "rad": (2, np.float32, 1),

@@ -184,3 +184,30 @@ def test_ensemble_members_equal_individual_runs(host, tmp_path):
             assert_bit_equal(states[k][key], solo.get(key), f"member {k} final {key}")
     # different seeds really are different blobs
     assert len({tuple(np.round(r[-1, 1:3], 5)) for r in rows}) == len(seeds)
+
+
+def test_exact_checkpoint_resume(host, tmp_path):
+    """saveCheckpoint/loadCheckpoint keep what the reference's CSV resume loses (phase,
+    dead flags, noise-draw counter, the generator, contact forces and the STALE slot layout), so a
+    resumed run is bit-identical to the uninterrupted one -- across a phase update with noise, with
+    dead bots drawn after the checkpoint."""
+    ck = str(tmp_path / "run.pbck")
+    over = dict(max_time="1e9", time_to_dead="9.0", sort_interval="5.0")
+    a = host.HostSim(EX("example_dead_cells.cfg"), **over)
+    a.advance(700)          # t = 7: two re-sorts behind us, stale lists in use
+    a.save_checkpoint(ck)
+    a.advance(900)          # dead draw at t = 9, phase update (noise) at t = 12, more re-sorts
+    b = host.HostSim(EX("example_dead_cells.cfg"), reset=False, **over)
+    b.load_checkpoint(ck)
+    assert abs(b.time - 7.0) < 1e-3
+    b.advance(900)
+    assert a.time == b.time
+    for k in ("pos", "vel", "rad", "phase"):
+        assert_bit_equal(a.get(k), b.get(k), k)
+    assert_bit_equal(a.get("dead"), b.get("dead"), "dead")
+    assert a.get("dead").sum() == 20
+    # a truncated file is rejected
+    open(ck, "r+b").truncate(100)
+    c = host.HostSim(EX("example_dead_cells.cfg"), reset=False, **over)
+    with pytest.raises(OSError):
+        c.load_checkpoint(ck)
