@@ -427,7 +427,7 @@ PB_DEV void pbPairEvalK(const PbContactK &P, const bool (&live)[K], float ax, fl
     ty[k] = gap < near2 ? band * ny[k] : fary;
     anyContact = anyContact || (contact[k] && live[k]);
   }
-  if (__builtin_amdgcn_ballot_w64(anyContact) != 0ull) {
+  if (__builtin_amdgcn_ballot_w64(anyContact) != 0ull) {  // wave-uniform
     float2 vb[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -440,21 +440,18 @@ PB_DEV void pbPairEvalK(const PbContactK &P, const bool (&live)[K], float ax, fl
       const float vn = pbDot(rvx, rvy, nx[k], ny[k]);
       const float tvx = rvx - vn * nx[k], tvy = rvy - vn * ny[k];
       const float ks = -P.spring * (reach[k] - dist[k]);
-      float cx = 0.0f, cy = 0.0f;
-      cx += ks * nx[k];
-      cy += ks * ny[k];
+      // The reference builds each term as `tempforce = (0,0); tempforce += ...`; the leading 0 +
+      // only turns a -0 into +0.  A term's sign of zero is unobservable: it is consumed by
+      // force += term (force is never -0, so adding either zero changes nothing) and by
+      // length(term) (squares), so the adds are dropped here.  (pbPair keeps them.)
+      float cx = ks * nx[k];
+      float cy = ks * ny[k];
       cx += P.damping * rvx;
       cy += P.damping * rvy;
       cx += P.shear * tvx;
       cy += P.shear * tvy;
-      tx[k] = contact[k] ? cx : 0.0f + tx[k];
-      ty[k] = contact[k] ? cy : 0.0f + ty[k];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      tx[k] = 0.0f + tx[k];  // `tempforce += ...` onto (0,0): turns -0 into +0
-      ty[k] = 0.0f + ty[k];
+      tx[k] = contact[k] ? cx : tx[k];
+      ty[k] = contact[k] ? cy : ty[k];
     }
   }
   float m2[K];
@@ -467,7 +464,7 @@ PB_DEV void pbPairEvalK(const PbContactK &P, const bool (&live)[K], float ax, fl
     out[k].contact = contact[k];
     if (FAST) {
       out[k].mag = pbSqrtFast(m2[k]);
-      anyTiny = anyTiny || (live[k] && pbTinyNonzero(m2[k]));
+      anyTiny = anyTiny || pbTinyNonzero(m2[k]);  // (a non-live lane's 0/0 is NaN: not "tiny")
     } else {
       out[k].mag = sqrtf(m2[k]);
     }

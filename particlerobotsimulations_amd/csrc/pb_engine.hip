@@ -206,26 +206,13 @@ __global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ 
 
   auto sweep = [&](auto fastTag) {
     constexpr bool FAST = decltype(fastTag)::value;
-    // all ten cell-table reads are issued together (one memory latency, not five)
-    uint32_t segLo[10], segHi[10];
-#pragma unroll
-    for (int dy = -2; dy <= 2; dy++) {
-      const uint32_t row = ((uint32_t)(gy + dy) & (P.gridY - 1u)) * GX;
-#pragma unroll
-      for (int sg = 0; sg < 2; sg++) {
-        const int si = (dy + 2) * 2 + sg;
-        segLo[si] = 0;
-        segHi[si] = 0;
-        if (sg < nseg) {
-          segLo[si] = cellS[row + (sg == 0 ? mx0 : 0u)];
-          segHi[si] = cellS[row + (sg == 0 ? mx0 + first : 5u - first)];
-        }
-      }
-    }
-#pragma unroll
+    // rolled on purpose: one copy of the pair loop in the binary (unrolling the five rows made ten)
+#pragma unroll 1
     for (int si = 0; si < 10; si++) {
       if ((si & 1) && nseg == 1) continue;  // second range of a row only exists at the x-wrap
-      const uint32_t lo = segLo[si], hi = segHi[si];
+      const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+      const uint32_t lo = cellS[row + ((si & 1) ? 0u : mx0)];
+      const uint32_t hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)];
       {
         if (FLAT) {
           // NB neighbours per trip, evaluated side by side (independent dependency chains for the
