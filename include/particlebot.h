@@ -99,6 +99,10 @@ class Particlebot {
   static void setVerbosePlacement(bool on);
   /* lattice pitch used by CONFIG_HEX placement; <= 0 selects the reference's 2*min_radius */
   void setHexSpacing(float pitch) { hexSpacing = pitch; }
+  /* Extension: place the bots on a centred square lattice (pitch as setHexSpacing) instead of what
+   * params.config says.  Unlike any hexagonal packing, four contacts per bot are numerically stable
+   * under the reference's parameters: the O(N) placement for very large arenas. */
+  void setSquareLattice(bool on) { squareLattice = on; }
   pbSim *engineHandle() { return sim; }
   /* host mirrors in original bot order (valid after reset(); refreshed by getArray/dump) */
   const float *hostPositions() const { return hPos; }
@@ -163,6 +167,7 @@ class Particlebot {
   float wallHalf = 64.0f;
   bool exitOnMaxTime = true;
   float hexSpacing = 0.0f;
+  bool squareLattice = false;
   PbLibcRand rng; /* seeded with params.seed at construction */
 };
 

@@ -627,6 +627,17 @@ void Particlebot::reset() {
   if (sim) pbSimSetTime(sim, 0.0f);
   const uint n = params.nCells;
   std::fill(hVelV.begin(), hVelV.end(), 0.0f);
+  if (squareLattice) {
+    // extension: side x side bots, row-major, centred on the origin
+    const uint side = (uint)ceilf(sqrtf((float)n));
+    const float pitch = hexSpacing > 0.0f ? hexSpacing : params.min_radius * 2.0f;
+    const float half = (float)(side - 1) * 0.5f;
+    for (uint i = 0; i < n; i++) {
+      hPos[2 * i] = ((float)(i % side) - half) * pitch;
+      hPos[2 * i + 1] = ((float)(i / side) - half) * pitch;
+    }
+    particlebotConfigSize.x = particlebotConfigSize.y = side;
+  } else
   switch (params.config) {
     case CONFIG_HEX:
       particlebotConfigSize.x = (int)ceilf(powf((float)n, 1.0f / 2.0f));

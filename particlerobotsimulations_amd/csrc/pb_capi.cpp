@@ -172,6 +172,7 @@ void *pbHostCreate(const char *cfg_path, const char *overrides, int engine) {
                            h->cfg.wallHalf());
   h->bot->setExitOnMaxTime(false);
   h->bot->setHexSpacing(h->cfg.hex_spacing);
+  h->bot->setSquareLattice(h->cfg.square_lattice);
   return h;
 }
 
@@ -301,6 +302,7 @@ void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const
     cfg->derive();
     Particlebot *bot = new Particlebot(cfg->params, Particlebot::Engine::HostOnly, cfg->wallHalf());
     bot->setHexSpacing(cfg->hex_spacing);
+    bot->setSquareLattice(cfg->square_lattice);
     bot->reset();
     e->bots.push_back(bot);
     params.push_back(bot->getParams());

@@ -67,6 +67,7 @@ PbRunConfig::PbRunConfig() {
   grid_size = 0;
   arena_half = 0.0f;
   hex_spacing = 0.0f;
+  square_lattice = false;
   repoint();
 }
 
@@ -177,6 +178,7 @@ void PbRunConfig::setParam(const std::string &name, const std::string &value) {
   else if (is("pb_arena_half", 13)) arena_half = f();
   else if (is("pb_hex_spacing", 14)) hex_spacing = f();
   else if (is("pb_placement", 12)) {
+    square_lattice = value.rfind("square", 0) == 0;
     if (value.rfind("hex", 0) == 0) params.config = CONFIG_HEX;
     else if (value.rfind("grid", 0) == 0) params.config = CONFIG_GRID;
     else if (value.rfind("line", 0) == 0) params.config = CONFIG_LINE;

@@ -18,7 +18,8 @@ struct PbRunConfig {
   // extensions (not in the reference): generalised arena
   unsigned grid_size;  // 0 -> 512 (main.cpp:937)
   float arena_half;    // 0 -> walls and world origin at +-64 (main.cpp:939, impl.cuh:75-97)
-  float hex_spacing;   // 0 -> 2*min_radius (particlebot.cpp:760); only used by hex placement
+  float hex_spacing;   // 0 -> 2*min_radius (particlebot.cpp:760); lattice pitch of hex / square placement
+  bool square_lattice; // pb_placement square
 
   PbRunConfig();
   // main.cpp:594-816: one name/value pair, prefix matching in source order, quirks included

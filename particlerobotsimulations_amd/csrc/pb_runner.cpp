@@ -53,6 +53,7 @@ int main(int argc, char **argv) {
   Particlebot sim(cfg.params, engine, cfg.wallHalf());
   sim.setExitOnMaxTime(false);
   sim.setHexSpacing(cfg.hex_spacing);
+  sim.setSquareLattice(cfg.square_lattice);
   sim.reset();
   const SimParams &p = sim.getParams();
   for (;;) {

@@ -106,7 +106,7 @@ def test_object_transport_cell_size_rule(host, orc):
 
 def test_extension_keys(host):
     c = host.load_config(os.path.join(ROOT, "examples", "million_bots.cfg"))
-    assert (c.gridSizeX, c.numCells, c.worldOriginX, c.wallHalf, c.config) == (2048, 2048 * 2048, -240.0, 240.0, 4)
+    assert (c.gridSizeX, c.numCells, c.worldOriginX, c.wallHalf, c.config) == (2048, 2048 * 2048, -240.0, 240.0, 0)
     assert c.nCells == 1_000_000
 
 

@@ -211,3 +211,16 @@ def test_exact_checkpoint_resume(host, tmp_path):
     c = host.HostSim(EX("example_dead_cells.cfg"), reset=False, **over)
     with pytest.raises(OSError):
         c.load_checkpoint(ck)
+
+
+def test_million_bot_cfg_runs_headless(tmp_path):
+    """examples/million_bots.cfg through the runner binary: generalised arena + square-lattice
+    placement + one fused kernel per step; the CSV centroid stays at the lattice centre."""
+    exe = os.path.join(ROOT, "particlerobotsimulations_amd", "bin", "particlebot_run")
+    out = tmp_path / "m.csv"
+    subprocess.check_call([exe, EX("million_bots.cfg"), "--quiet", "--set", "max_time", "0.5", "--set",
+                           "dump_interval", "0.25", "--set", "csv_filename", str(out)], cwd=str(tmp_path), timeout=600)
+    rows = [r for r in out.read_text().strip().split("\n")[2:]]
+    assert len(rows) >= 3
+    last = [float(x) for x in rows[-1].strip(",").split(",")]
+    assert abs(last[1]) < 1e-3 and abs(last[2]) < 1e-3 and 229.9 < last[3] < 230.1
