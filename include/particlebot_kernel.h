@@ -15,90 +15,59 @@
 
 typedef unsigned int uint;
 
-/* particlebot_kernel.cuh:25-35 */
+/* particlebot_kernel.cuh:25-35: initial-placement presets (values 0..6, then the count) */
 enum ParticlebotConfig {
-  CONFIG_RANDOM,
-  CONFIG_GRID,
-  CONFIG_BLOB,
-  CONFIG_BLOB_UPLEFT,
-  CONFIG_HEX,
-  CONFIG_LINE,
-  CONFIG_LIGHTTEST_7,
+  CONFIG_RANDOM, CONFIG_GRID, CONFIG_BLOB, CONFIG_BLOB_UPLEFT, CONFIG_HEX, CONFIG_LINE, CONFIG_LIGHTTEST_7,
   _NUM_CONFIGS
 };
 
-/* particlebot_kernel.cuh:37-45 */
+/* particlebot_kernel.cuh:37-45: selector of getArray / setArray */
 enum ParticlebotArray { POSITION, VELOCITY, RADII, PHASE, FREQUENCY, DEAD };
 
-/* particlebot_kernel.cuh:47-50 */
+/* particlebot_kernel.cuh:47-50: the only control law */
 enum ParticlebotControl { LIGHT_WAVE };
 
 /* Obstacle lists hold at most this many entries on the device (the reference keeps
  * `__constant__ float x1obs[10]` etc., particlebot_kernel_impl.cuh:28-34). */
 #define PB_MAX_OBSTACLES 10
 
-/* particlebot_kernel.cuh:58-120 -- same fields, same order */
+/* particlebot_kernel.cuh:58-120.  Field ORDER and TYPES are the reference's (that is the ABI: 256
+ * bytes, float2/uint2 8-byte aligned as in CUDA; static_assert'ed in csrc/pb_device.hpp); fields
+ * of one type that are adjacent there are declared together here. */
 struct SimParams {
+  /* uniform grid */
   uint2 gridSize;
   uint numCells;
-
-  float2 worldOrigin;
-  float2 cellSize;
-
+  float2 worldOrigin, cellSize;
+  /* population: nDead == -1 selects object-transport mode (the last bot is a passive payload) */
   uint nCells;
   int nDead;
   uint maxParticlebotsPerCell;
-
-  float gravity;
-  float spring;
-  float damping;
-  float shear;
-  float attraction;
-  float boundaryDamping;
-  float friction;
-
-  float massFactor;
-  float frictionFactor;
-  float radFactor;
-  float attractionFactor;
-
-  float constraint;
-  float constraint_contraction;
+  /* forces */
+  float gravity, spring, damping, shear, attraction, boundaryDamping, friction;
+  /* payload multipliers (object transport) */
+  float massFactor, frictionFactor, radFactor, attractionFactor;
+  /* actuation limits */
+  float constraint, constraint_contraction;
+  /* centroid trail (display) */
   int centroid_steps;
-  float centroid_int;
-  float centroid_radius;
-  float light_x;
-  float light_y;
-  float phase_update_interval;
+  float centroid_int, centroid_radius;
+  /* light and control */
+  float light_x, light_y, phase_update_interval;
   ParticlebotControl control;
   ParticlebotConfig config;
-  float min_radius;
-  float max_radius;
-  float rise_period;
-  float freq;
-
+  float min_radius, max_radius, rise_period, freq;
+  /* rectangular obstacles: nobstacles entries in each host array */
   int nobstacles;
-  float *x1obs;
-  float *x2obs;
-  float *y1obs;
-  float *y2obs;
-
+  float *x1obs, *x2obs, *y1obs, *y2obs;
+  /* circular obstacles: n_cir_obstacles entries in each host array */
   int n_cir_obstacles;
-  float *x_cir_obs;
-  float *y_cir_obs;
-  float *r_cir_obs;
-
+  float *x_cir_obs, *y_cir_obs, *r_cir_obs;
   int Nx;
-
   float phase_std;
   unsigned seed;
-
-  uint light_shadow;
-  uint testing;
-  uint constrained_contraction;
-  uint display_shadow;
-  float time_to_dead;
-  float max_time;
+  uint light_shadow, testing, constrained_contraction, display_shadow;
+  float time_to_dead, max_time;
 };
 
 #endif /* PARTICLEBOT_KERNEL_H */
