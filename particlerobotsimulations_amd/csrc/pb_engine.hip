@@ -52,6 +52,12 @@ thread_local std::string g_lastError;
 #define PB_TILE 256
 #endif
 constexpr int TILE = PB_TILE;
+#ifndef PB_FORCE_WAVES
+#define PB_FORCE_WAVES 1
+#endif
+#ifndef PB_THROUGHPUT_NB
+#define PB_THROUGHPUT_NB 1
+#endif
 // NB (template parameter of k_force): neighbours evaluated side by side per loop trip.  1 is the
 // throughput form (8 waves/SIMD, the VALU pipe is the limit); 4 is used for batches too small to
 // fill the chip, where a lone wave's dependent-issue latency is the limit and ILP pays.
@@ -111,7 +117,7 @@ struct GroupSum<L, L> {
 // (ds_swizzle broadcasts inside the group), so the sums -- and their order -- are those of L == 1.
 // The serial chain per bot shrinks ~L/2-fold at ~2x the total VALU work.
 template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB>
-__global__ __launch_bounds__(TILE) void k_force(const PbDevParams *__restrict__ params,
+__global__ __launch_bounds__(TILE, PB_FORCE_WAVES) void k_force(const PbDevParams *__restrict__ params,
                                                 const float4 *__restrict__ prIn, const float2 *__restrict__ velIn,
                                                 float4 *__restrict__ prOut, float2 *__restrict__ velOut,
                                                 const float *__restrict__ phase, const int *__restrict__ dead,
@@ -656,7 +662,7 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
   if (fuse == F && payload == PL && kind == K) {                                                         \
     if (FL && form == 2) return launchForceT<F, PL, FL, FA, (FL ? 8 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 1) return launchForceT<F, PL, FL, FA, 1, (FL ? 4 : 1)>(S, c, o, dt, tNext, doRadiusNext); \
-    return launchForceT<F, PL, FL, FA, 1, 1>(S, c, o, dt, tNext, doRadiusNext);                            \
+    return launchForceT<F, PL, FL, FA, 1, (FL ? PB_THROUGHPUT_NB : 1)>(S, c, o, dt, tNext, doRadiusNext);                            \
   }
   PB_CASE(true, true, 0, false, false)
   PB_CASE(true, true, 1, true, false)
