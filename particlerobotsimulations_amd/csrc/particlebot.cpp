@@ -372,6 +372,7 @@ float *Particlebot::getArray(ParticlebotArray array) {
     case VELOCITY: pullState(false, true, false); return hVel;
     case RADII: pullState(false, false, true); return hRad;
     case PHASE:
+      if (engineKind == Engine::HostOnly) return hphase;
       if (engineKind == Engine::Fused) {
         if (pbSimGetState(sim, nullptr, nullptr, nullptr, hphase, nullptr, nullptr, nullptr) != PB_OK)
           die("pbSimGetState");
@@ -383,6 +384,7 @@ float *Particlebot::getArray(ParticlebotArray array) {
 }
 
 int *Particlebot::getDeadArray() {
+  if (engineKind == Engine::HostOnly) return hDead;
   if (engineKind == Engine::Fused) {
     if (pbSimGetState(sim, nullptr, nullptr, nullptr, nullptr, hDead, nullptr, nullptr) != PB_OK) die("pbSimGetState");
   } else {
@@ -620,9 +622,9 @@ void Particlebot::placeRandom() {
 }
 
 void Particlebot::reset() {
-  // particlebot.cpp:485-801.  CONFIG_RANDOM, CONFIG_HEX, CONFIG_GRID and CONFIG_LINE are built;
-  // the three hard-coded 10-bot presets (:492-611) are not (they assert nCells == 10 and are
-  // unreachable from a .cfg: the config key never takes effect, main.cpp:794-809).
+  // particlebot.cpp:485-801: every ParticlebotConfig value (from a .cfg only CONFIG_RANDOM is
+  // reachable in the reference -- the config key never takes effect, main.cpp:794-809 -- the
+  // extension key pb_placement selects the others).
   time = 0;
   if (sim) pbSimSetTime(sim, 0.0f);
   const uint n = params.nCells;
@@ -654,6 +656,27 @@ void Particlebot::reset() {
       particlebotConfigSize.y = 1;
       initGrid(particlebotConfigSize, params.min_radius * 2.0f, params.max_radius * 0.00f, n);
       break;
+    case CONFIG_BLOB:
+    case CONFIG_BLOB_UPLEFT:
+    case CONFIG_LIGHTTEST_7: {
+      // particlebot.cpp:492-611: three hand-laid 10-bot clusters on a triangular lattice of pitch
+      // 2*min_radius (the reference asserts nCells == 10; extra bots here stay at the origin).
+      // Entries are (x, y) in units of r: plain numbers, or k = 1 + sqrt3 / s = sqrt3 multiples.
+      const float r = params.min_radius, s3 = powf(3.0f, 0.5f);
+      const float k = -(1.0f + s3) * r, K = (1.0f + s3) * r, s = s3 * r, S = -s3 * r, s2 = s3 * 2.0f * r;
+      const float blob[10][2] = {{r, -r}, {r, r}, {-r, -r}, {-r, r}, {k, 0.0f}, {0.0f, k}, {0.0f, K},
+                                 {2.0f * r, k}, {2.0f * r, K}, {K, 0.0f}};
+      const float upleft[10][2] = {{-r, r}, {r, r}, {-r, -r}, {r, -r}, {0.0f, k}, {k, 0.0f}, {K, 0.0f},
+                                   {k, 2.0f * r}, {K, 2.0f * r}, {0.0f, K}};
+      const float light7[10][2] = {{0.0f, 0.0f}, {S, r}, {s, -r}, {s, r}, {0.0f, 2.0f * r}, {S, -r}, {0.0f, -2.0f * r},
+                                   {s, 3.0f * r}, {0.0f, 4.0f * r}, {s2, 2.0f * r}};
+      const float(*t)[2] = params.config == CONFIG_BLOB ? blob : params.config == CONFIG_BLOB_UPLEFT ? upleft : light7;
+      for (uint i = 0; i < n && i < 10; i++) {
+        hPos[2 * i] = t[i][0];
+        hPos[2 * i + 1] = t[i][1];
+      }
+      particlebotConfigSize.x = particlebotConfigSize.y = 4;
+    } break;
     case CONFIG_RANDOM:
     default:
       placeRandom();

@@ -168,7 +168,11 @@ void *pbHostCreate(const char *cfg_path, const char *overrides, int engine) {
   applyOverrides(h->cfg, overrides);
   h->cfg.derive();
   srand(h->cfg.params.seed);  // main.cpp:929
-  h->bot = new Particlebot(h->cfg.params, engine ? Particlebot::Engine::Legacy : Particlebot::Engine::Fused,
+  // engine: 0 fused, 1 legacy, 2 host only (placement and draws without any device: CPU tests)
+  h->bot = new Particlebot(h->cfg.params,
+                           engine == 2   ? Particlebot::Engine::HostOnly
+                           : engine == 1 ? Particlebot::Engine::Legacy
+                                         : Particlebot::Engine::Fused,
                            h->cfg.wallHalf());
   h->bot->setExitOnMaxTime(false);
   h->bot->setHexSpacing(h->cfg.hex_spacing);
@@ -238,6 +242,14 @@ int pbHostLoadCheckpoint(void *hv, const char *path) {
   const bool ok = ((HostSim *)hv)->bot->loadCheckpoint(fp);
   fclose(fp);
   return ok ? 0 : -2;
+}
+
+// draws the dead set now (what update() does at time_to_dead) and returns it; host mirrors only
+int pbHostDrawDead(void *hv, int *out) {
+  HostSim *h = (HostSim *)hv;
+  const int *d = h->bot->drawDeadBotsNow();
+  memcpy(out, d, sizeof(int) * h->bot->getParams().nCells);
+  return 0;
 }
 
 // which: 0 POSITION (2n floats) 1 VELOCITY (2n) 2 RADII (n) 3 PHASE (n) 5 DEAD (n ints)

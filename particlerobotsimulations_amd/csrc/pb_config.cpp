@@ -182,6 +182,9 @@ void PbRunConfig::setParam(const std::string &name, const std::string &value) {
     if (value.rfind("hex", 0) == 0) params.config = CONFIG_HEX;
     else if (value.rfind("grid", 0) == 0) params.config = CONFIG_GRID;
     else if (value.rfind("line", 0) == 0) params.config = CONFIG_LINE;
+    else if (value.rfind("blob_upleft", 0) == 0) params.config = CONFIG_BLOB_UPLEFT;
+    else if (value.rfind("blob", 0) == 0) params.config = CONFIG_BLOB;
+    else if (value.rfind("lighttest7", 0) == 0) params.config = CONFIG_LIGHTTEST_7;
     else params.config = CONFIG_RANDOM;
   }
   // anything else: the value line is consumed and ignored, as in the reference

@@ -75,6 +75,7 @@ def lib():
     L.pbHostDump.restype = C.c_int
     L.pbHostLoadFromFile.argtypes = [C.c_void_p, C.c_char_p]
     L.pbHostLoadFromFile.restype = C.c_int
+    L.pbHostDrawDead.argtypes = [C.c_void_p, C.c_void_p]
     L.pbHostSaveCheckpoint.argtypes = [C.c_void_p, C.c_char_p]
     L.pbHostSaveCheckpoint.restype = C.c_int
     L.pbHostLoadCheckpoint.argtypes = [C.c_void_p, C.c_char_p]
@@ -117,7 +118,7 @@ class HostSim:
 
     def __init__(self, cfg_path=None, engine="fused", reset=True, **over):
         self._h = lib().pbHostCreate(os.fsencode(cfg_path) if cfg_path else None, _overrides(over),
-                                     1 if engine == "legacy" else 0)
+                                     {"fused": 0, "legacy": 1, "host": 2}[engine])
         if not self._h:
             raise FileNotFoundError(cfg_path)
         self.n = lib().pbHostNumBots(self._h)
@@ -159,6 +160,11 @@ class HostSim:
     def load_from_file(self, path):
         if lib().pbHostLoadFromFile(self._h, os.fsencode(path)) != 0:
             raise OSError(path)
+
+    def draw_dead(self):
+        out = np.empty(self.n, np.int32)
+        lib().pbHostDrawDead(self._h, out.ctypes.data_as(C.c_void_p))
+        return out
 
     def save_checkpoint(self, path):
         rc = lib().pbHostSaveCheckpoint(self._h, os.fsencode(path))
