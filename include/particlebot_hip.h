@@ -123,6 +123,7 @@ typedef struct pbSimStats {
   unsigned long long state_launches; /* stand-alone radius+integrate kernel */
   unsigned long long resorts;
   unsigned long long phase_updates;
+  unsigned long long resident_launches; /* multi-step one-workgroup-per-simulation kernel */
 } pbSimStats;
 
 const char *pbGetLastErrorString(void);
@@ -194,11 +195,16 @@ int pbSimSetResortEveryStep(pbSim *sim, int on);
  * with the fast exact sqrt/division forms (default; falls back to 1 when the simulation's
  * constants are outside their proven domain).  All variants give bit-identical results. */
 int pbSimSetForceVariant(pbSim *sim, int variant);
-/* Shape of the force kernel's neighbour loop: 1 = throughput form (one bot per lane, one neighbour
- * per trip); 4 = four neighbours evaluated side by side (ILP, for batches too small to fill the
- * chip); 8 = eight lanes per bot (tiny batches); 0 = automatic (default).  Results do not depend
- * on it. */
+/* Lanes per bot in the per-step force kernel: 1 = throughput form (one bot per lane); 2, 4, 8 =
+ * that many adjacent lanes share a bot's neighbour list and add the terms in list order (batches
+ * too small to fill the chip: the serial neighbour loop is the limit); 0 = automatic (default:
+ * 8 up to 49152 bots in the batch, 4 up to 131072, else 1).  Results do not depend on it. */
 int pbSimSetLanesPerBot(pbSim *sim, int lanes);
+/* Resident form for simulations of at most 1024 bots: one workgroup per simulation keeps the state
+ * in registers/LDS and runs every timestep up to the next re-sort, phase update or end of the
+ * pbSimStep call in ONE launch.  0 = automatic (default: used when nbots <= 512, or <= 1024 in a
+ * batch of at least 64), 1 = never, 2 = whenever the simulation fits.  Results do not depend on it. */
+int pbSimSetResident(pbSim *sim, int mode);
 
 /* On-device check that the fast exact forms equal the compiler's IEEE sqrtf and division: every
  * float in the sqrt domain, and div_samples sampled (numerator, numerator, denominator) triples

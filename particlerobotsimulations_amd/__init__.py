@@ -227,6 +227,10 @@ class Sim:
     def set_lanes_per_bot(self, lanes):
         _capi.check(_capi.lib().pbSimSetLanesPerBot(self._h, int(lanes)))
 
+    def set_resident(self, mode):
+        """0 automatic, 1 never, 2 whenever the simulation fits one workgroup (<= 1024 bots)."""
+        _capi.check(_capi.lib().pbSimSetResident(self._h, int(mode)))
+
     def set_resort_every_step(self, on):
         _capi.check(_capi.lib().pbSimSetResortEveryStep(self._h, 1 if on else 0))
 

@@ -62,7 +62,8 @@ class pbRngState(C.Structure):
 class pbSimStats(C.Structure):
     _fields_ = [("steps", C.c_ulonglong), ("fused_launches", C.c_ulonglong),
                 ("plain_launches", C.c_ulonglong), ("state_launches", C.c_ulonglong),
-                ("resorts", C.c_ulonglong), ("phase_updates", C.c_ulonglong)]
+                ("resorts", C.c_ulonglong), ("phase_updates", C.c_ulonglong),
+                ("resident_launches", C.c_ulonglong)]
 
 
 # every symbol include/particlebot_hip.h declares: name -> (restype, argtypes)
@@ -123,6 +124,7 @@ SYMBOLS = {
     "pbSimSetResortEveryStep": (_I, [_VP, _I]),
     "pbSimSetForceVariant": (_I, [_VP, _I]),
     "pbSimSetLanesPerBot": (_I, [_VP, _I]),
+    "pbSimSetResident": (_I, [_VP, _I]),
     "pbSelfTest": (_I, [C.c_ulonglong] + [C.POINTER(C.c_ulonglong)] * 4),
 }
 

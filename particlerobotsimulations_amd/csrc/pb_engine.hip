@@ -58,9 +58,9 @@ constexpr int TILE = PB_TILE;
 #ifndef PB_THROUGHPUT_NB
 #define PB_THROUGHPUT_NB 1
 #endif
-// NB (template parameter of k_force): neighbours evaluated side by side per loop trip.  1 is the
-// throughput form (8 waves/SIMD, the VALU pipe is the limit); 4 is used for batches too small to
-// fill the chip, where a lone wave's dependent-issue latency is the limit and ILP pays.
+// NB (template parameter of k_force): neighbours evaluated side by side per loop trip of the
+// one-lane-per-bot form.  1 is what ships (8 waves/SIMD, the VALU pipe is the limit); larger values
+// (more ILP per wave) measured no better at any size and are a build-time experiment only.
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
@@ -84,11 +84,6 @@ __global__ __launch_bounds__(TILE) void k_state(const PbDevParams *__restrict__ 
   vel[s] = v;
 }
 
-// Forces + kick of step n (impl.cuh:657-831); with FUSE also radius + integration of step n+1.
-// PAYLOAD: object-transport mode (nDead == -1), per-pair attraction factors.  FLAT: branch-free
-// pair evaluation (pbPairFlat) instead of the reference-shaped branches (pbPair).
-// FASTOK: the simulation passed pbFastMathAllowed, so waves whose lanes all pass
-// pbLaneFastMathOk may use the exact fast sqrt/division forms.
 // Ordered sum over the L lanes of a group: term e of the group is broadcast to all its lanes with
 // ds_swizzle in bit-mask mode (source lane = (lane & and_mask) | e, inside each 32-lane half; the
 // pattern must be an immediate, hence the compile-time recursion) and added, e = 0 .. L-1.
@@ -111,11 +106,168 @@ struct GroupSum<L, L> {
   static __device__ __forceinline__ void add(const PbPairTerm &, int, PbForce &) {}
 };
 
+// Flattened neighbour list of one bot (L > 1 form): plain scalars passed by value, so that they
+// stay in registers wherever the sweep is inlined (arrays or by-reference captures here ended up in
+// scratch memory with data-dependent indices).
+struct PbSegList {
+  uint32_t o0, o1, o2, o3, o4, o5, o6, o7, o8, o9;  // slot = list position + o_r inside segment r
+  uint32_t c1, c2, c3, c4, c5, c6, c7, c8, c9;      // first list position of segments 1..9
+  __device__ __forceinline__ void set(int r, uint32_t off, uint32_t start) {
+    switch (r) {
+      case 0: o0 = off; break;
+      case 1: o1 = off, c1 = start; break;
+      case 2: o2 = off, c2 = start; break;
+      case 3: o3 = off, c3 = start; break;
+      case 4: o4 = off, c4 = start; break;
+      case 5: o5 = off, c5 = start; break;
+      case 6: o6 = off, c6 = start; break;
+      case 7: o7 = off, c7 = start; break;
+      case 8: o8 = off, c8 = start; break;
+      default: o9 = off, c9 = start; break;
+    }
+  }
+};
+__device__ __forceinline__ uint32_t pbSegSlot(const PbSegList SL, uint32_t m, uint32_t self, uint32_t k) {
+  uint32_t o = SL.o0;
+  o = k >= SL.c1 ? SL.o1 : o;
+  o = k >= SL.c2 ? SL.o2 : o;
+  o = k >= SL.c3 ? SL.o3 : o;
+  o = k >= SL.c4 ? SL.o4 : o;
+  o = k >= SL.c5 ? SL.o5 : o;
+  o = k >= SL.c6 ? SL.o6 : o;
+  o = k >= SL.c7 ? SL.o7 : o;
+  o = k >= SL.c8 ? SL.o8 : o;
+  o = k >= SL.c9 ? SL.o9 : o;
+  return k < m ? k + o : self;  // beyond the list: the bot's own slot, never accumulated
+}
+
+// Neighbour sweep of one bot: the 25-cell stencil as 5 grid rows x up to 2 slot ranges (x-wrap), in
+// the reference's order (impl.cuh:617-655).  prIn/velIn are indexed by (global slot - base): the
+// per-step kernel passes the HBM arrays and base 0, the resident kernel its LDS copy and the
+// simulation's first slot.  s is the bot's own index into prIn.
 // L: lanes per bot.  L == 1 is the throughput form (one bot per lane).  L > 1 (small batches that
 // cannot fill the chip) gives each bot L adjacent lanes: they evaluate L candidates of the bot's
 // flattened neighbour list at a time, then every lane of the group adds the L terms in list order
 // (ds_swizzle broadcasts inside the group), so the sums -- and their order -- are those of L == 1.
 // The serial chain per bot shrinks ~L/2-fold at ~2x the total VALU work.
+template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, class PR, class VL>
+__device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
+                                        const uint32_t *__restrict__ cellS, uint32_t base, uint32_t s,
+                                        uint32_t sub, const float4 &me, const float2 &v, float att1, PbForce &F) {
+  const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
+  const float slope0 = pbBandSlope(P.attraction);
+  const float attraction0 = P.attraction;
+  const PbContactK CK{P.spring, P.damping, P.shear};
+  const uint32_t GX = P.gridX;
+  const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
+  const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;  // cells before the x-wrap
+  const int nseg = first < 5u ? 2 : 1;
+  if (L > 1) {
+    // ---- flattened candidate list, L candidates per trip, ordered group sum --------------------
+    // 5 grid rows x up to 2 ranges (x-wrap) = 10 list segments; segment r covers list positions
+    // [c[r], c[r+1]) and maps position k to slot k + o[r].
+    PbSegList SL;
+    uint32_t cum = 0;
+#pragma unroll
+    for (int si = 0; si < 10; si++) {
+      const int sg = si & 1;
+      const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+      uint32_t lo = 0, hi = 0;
+      if (sg < nseg) {
+        lo = cellS[row + (sg == 0 ? mx0 : 0u)] - base;
+        hi = cellS[row + (sg == 0 ? mx0 + first : 5u - first)] - base;
+      }
+      SL.set(si, lo - cum, cum);
+      cum += hi - lo;
+    }
+    const uint32_t m = cum;
+    auto slotOf = [=](uint32_t k) __attribute__((always_inline)) { return pbSegSlot(SL, m, s, k); };
+    uint32_t jn = slotOf(sub);
+    float4 qn = prIn[jn];
+    for (uint32_t b0 = 0; b0 < m; b0 += L) {
+      const uint32_t j = jn;
+      const float4 q = qn;
+      jn = slotOf(b0 + L + sub);
+      qn = prIn[jn];
+      const bool live[1] = {j != s};
+      const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
+      const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
+      const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
+      PbPairTerm t[1];
+      pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
+                           [&](int) { return velIn[j]; }, t);
+      const int flags = (live[0] ? 1 : 0) | (t[0].contact ? 2 : 0);
+      // every lane of the group adds the group's L terms in list order
+      GroupSum<L, 0>::add(t[0], flags, F);
+    }
+    return;
+  }
+  // rolled on purpose: one copy of the pair loop in the binary (unrolling the five rows made ten)
+#pragma unroll 1
+  for (int si = 0; si < 10; si++) {
+    if ((si & 1) && nseg == 1) continue;  // second range of a row only exists at the x-wrap
+    const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+    const uint32_t lo = cellS[row + ((si & 1) ? 0u : mx0)] - base;
+    const uint32_t hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base;
+    if (FLAT) {
+      // NB neighbours per trip, evaluated side by side (independent dependency chains for the
+      // scheduler to interleave) and then summed in slot order.  The next trip's posrad loads
+      // are already in flight (software pipeline).  Out-of-range slots alias the lane's own
+      // slot s, which is never accumulated.  With NB > 1 (latency form) the neighbours'
+      // velocities travel with their posrad instead of being fetched inside the contact branch.
+      constexpr bool PREVEL = NB > 1;
+      float4 q[NB];
+      float2 vq[NB];
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        const uint32_t i0 = lo + k < hi ? lo + k : s;
+        q[k] = prIn[i0];
+        if (PREVEL) vq[k] = velIn[i0];
+      }
+      for (uint32_t j = lo; j < hi; j += NB) {
+        bool live[NB];
+        uint32_t idx[NB];
+        float bx[NB], by[NB], rb[NB], A[NB], K[NB];
+        float2 vb[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+          idx[k] = j + k < hi ? j + k : s;
+          live[k] = idx[k] != s;
+          bx[k] = q[k].x;
+          by[k] = q[k].y;
+          rb[k] = q[k].z;
+          if (PREVEL) vb[k] = vq[k];
+          // payload factors ride in q.w / att1 (impl.cuh:629-633, 640-649)
+          A[k] = PAYLOAD ? attraction0 * q[k].w * att1 : attraction0;
+          K[k] = PAYLOAD ? pbBandSlope(A[k]) : slope0;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+          const uint32_t i1 = j + NB + k < hi ? j + NB + k : s;
+          q[k] = prIn[i1];
+          if (PREVEL) vq[k] = velIn[i1];
+        }
+        PbPairTerm t[NB];
+        pbPairEvalK<FAST, NB>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
+                              [&](int k) { return PREVEL ? vb[k] : velIn[idx[k]]; }, t);
+#pragma unroll
+        for (int k = 0; k < NB; k++) pbPairAdd(live[k], t[k], F);
+      }
+    } else {
+      for (uint32_t j = lo; j < hi; j++) {
+        const float4 q = prIn[j];
+        const float A = PAYLOAD ? P.attraction * q.w * att1 : P.attraction;
+        if (j != s) pbPair(P, me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, A, [&]() { return velIn[j]; }, F);
+      }
+    }
+  }
+}
+
+// Forces + kick of step n (impl.cuh:657-831); with FUSE also radius + integration of step n+1.
+// PAYLOAD: object-transport mode (nDead == -1), per-pair attraction factors.  FLAT: branch-free
+// pair evaluation instead of the reference-shaped branches (pbPair).
+// FASTOK: the simulation passed pbFastMathAllowed, so waves whose lanes all pass
+// pbLaneFastMathOk may use the exact fast sqrt/division forms.
 template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB>
 __global__ __launch_bounds__(TILE, PB_FORCE_WAVES) void k_force(const PbDevParams *__restrict__ params,
                                                 const float4 *__restrict__ prIn, const float2 *__restrict__ velIn,
@@ -138,7 +290,6 @@ __global__ __launch_bounds__(TILE, PB_FORCE_WAVES) void k_force(const PbDevParam
 
   const float4 me = prIn[s];
   float2 v = velIn[s];
-  const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
   bool selfPayload = false;
   if (PAYLOAD) selfPayload = (orig[s] == P.nCells - 1u);
   const float att1 = selfPayload ? P.attractionFactor : 1.0f;
@@ -149,136 +300,11 @@ __global__ __launch_bounds__(TILE, PB_FORCE_WAVES) void k_force(const PbDevParam
   F.fa = 0.0f;
   F.fr = 0.0f * absR[s];  // impl.cuh:688
 
-  const float slope0 = pbBandSlope(P.attraction);
-  const float attraction0 = P.attraction;
-  const PbContactK CK{P.spring, P.damping, P.shear};
-  const uint32_t GX = P.gridX;
-  const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
-  const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;  // cells before the x-wrap
-  const int nseg = first < 5u ? 2 : 1;
-  // ---- L > 1: flattened candidate list, L candidates per trip, ordered group sum --------------
-  auto sweepML = [&](auto fastTag) {
-    constexpr bool FAST = decltype(fastTag)::value;
-    constexpr int SEG = 10;  // 5 grid rows x up to 2 ranges (x-wrap)
-    uint32_t off[SEG], cum[SEG + 1];
-    cum[0] = 0;
-#pragma unroll
-    for (int dy = -2; dy <= 2; dy++) {
-      const uint32_t row = ((uint32_t)(gy + dy) & (P.gridY - 1u)) * GX;
-#pragma unroll
-      for (int sg = 0; sg < 2; sg++) {
-        const int si = (dy + 2) * 2 + sg;
-        uint32_t lo = 0, hi = 0;
-        if (sg < nseg) {
-          const uint32_t c0 = sg == 0 ? mx0 : 0u;
-          const uint32_t c1 = sg == 0 ? mx0 + first : 5u - first;
-          lo = cellS[row + c0];
-          hi = cellS[row + c1];
-        }
-        off[si] = lo - cum[si];  // slot of list position k inside this range: k + off
-        cum[si + 1] = cum[si] + (hi - lo);
-      }
-    }
-    const uint32_t m = cum[SEG];
-    auto slotOf = [&](uint32_t k) {
-      uint32_t o = off[0];
-#pragma unroll
-      for (int r = 1; r < SEG; r++) o = k >= cum[r] ? off[r] : o;
-      return k < m ? k + o : s;  // beyond the list: the bot's own slot, never accumulated
-    };
-    uint32_t jn = slotOf(sub);
-    float4 qn = prIn[jn];
-    for (uint32_t base = 0; base < m; base += L) {
-      const uint32_t j = jn;
-      const float4 q = qn;
-      jn = slotOf(base + L + sub);
-      qn = prIn[jn];
-      const bool live[1] = {j != s};
-      const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
-      const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
-      const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
-      PbPairTerm t[1];
-      pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
-                           [&](int) { return velIn[j]; }, t);
-      const int flags = (live[0] ? 1 : 0) | (t[0].contact ? 2 : 0);
-      // every lane of the group adds the group's L terms in list order
-      GroupSum<L, 0>::add(t[0], flags, F);
-    }
-  };
-  if (L > 1) {
-    if (FASTOK && __all(pbLaneFastMathOk(me.x, me.y))) sweepML(std::true_type{});
-    else sweepML(std::false_type{});
-  }
-
-  auto sweep = [&](auto fastTag) {
-    constexpr bool FAST = decltype(fastTag)::value;
-    // rolled on purpose: one copy of the pair loop in the binary (unrolling the five rows made ten)
-#pragma unroll 1
-    for (int si = 0; si < 10; si++) {
-      if ((si & 1) && nseg == 1) continue;  // second range of a row only exists at the x-wrap
-      const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
-      const uint32_t lo = cellS[row + ((si & 1) ? 0u : mx0)];
-      const uint32_t hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)];
-      {
-        if (FLAT) {
-          // NB neighbours per trip, evaluated side by side (independent dependency chains for the
-          // scheduler to interleave) and then summed in slot order.  The next trip's posrad loads
-          // are already in flight (software pipeline).  Out-of-range slots alias the lane's own
-          // slot s, which is never accumulated.  With NB > 1 (latency form) the neighbours'
-          // velocities travel with their posrad instead of being fetched inside the contact branch.
-          constexpr bool PREVEL = NB > 1;
-          float4 q[NB];
-          float2 vq[NB];
-#pragma unroll
-          for (int k = 0; k < NB; k++) {
-            const uint32_t i0 = lo + k < hi ? lo + k : s;
-            q[k] = prIn[i0];
-            if (PREVEL) vq[k] = velIn[i0];
-          }
-          for (uint32_t j = lo; j < hi; j += NB) {
-            bool live[NB];
-            uint32_t idx[NB];
-            float bx[NB], by[NB], rb[NB], A[NB], K[NB];
-            float2 vb[NB];
-#pragma unroll
-            for (int k = 0; k < NB; k++) {
-              idx[k] = j + k < hi ? j + k : s;
-              live[k] = idx[k] != s;
-              bx[k] = q[k].x;
-              by[k] = q[k].y;
-              rb[k] = q[k].z;
-              if (PREVEL) vb[k] = vq[k];
-              // payload factors ride in q.w / att1 (impl.cuh:629-633, 640-649)
-              A[k] = PAYLOAD ? attraction0 * q[k].w * att1 : attraction0;
-              K[k] = PAYLOAD ? pbBandSlope(A[k]) : slope0;
-            }
-#pragma unroll
-            for (int k = 0; k < NB; k++) {
-              const uint32_t i1 = j + NB + k < hi ? j + NB + k : s;
-              q[k] = prIn[i1];
-              if (PREVEL) vq[k] = velIn[i1];
-            }
-            PbPairTerm t[NB];
-            pbPairEvalK<FAST, NB>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
-                                  [&](int k) { return PREVEL ? vb[k] : velIn[idx[k]]; }, t);
-#pragma unroll
-            for (int k = 0; k < NB; k++) pbPairAdd(live[k], t[k], F);
-          }
-        } else {
-          for (uint32_t j = lo; j < hi; j++) {
-            const float4 q = prIn[j];
-            const float A = PAYLOAD ? P.attraction * q.w * att1 : P.attraction;
-            if (j != s) pbPair(P, me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, A, [&]() { return velIn[j]; }, F);
-          }
-        }
-      }
-    }
-  };
   // wave-uniform choice: the fast exact forms need every lane's coordinates away from zero
-  if (L == 1) {
-    if (FLAT && FASTOK && __all(pbLaneFastMathOk(me.x, me.y))) sweep(std::true_type{});
-    else sweep(std::false_type{});
-  }
+  if (FLAT && FASTOK && __all(pbLaneFastMathOk(me.x, me.y)))
+    pbSweep<PAYLOAD, FLAT, true, L, NB>(P, prIn, velIn, cellS, 0u, s, sub, me, v, att1, F);
+  else
+    pbSweep<PAYLOAD, FLAT, false, L, NB>(P, prIn, velIn, cellS, 0u, s, sub, me, v, att1, F);
   pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
   pbFrictionAndKick(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
 
@@ -292,6 +318,88 @@ __global__ __launch_bounds__(TILE, PB_FORCE_WAVES) void k_force(const PbDevParam
     velOut[s] = v;
     absA[s] = F.fa;
     absR[s] = F.fr;
+  }
+}
+
+// Resident form for small simulations: ONE workgroup per simulation keeps its bots in registers
+// (L lanes per bot) and the positions/velocities the neighbours read in LDS (ping-pong), and runs
+// nsteps whole timesteps in one launch with one workgroup barrier per step.  A per-step launch of
+// a few hundred bots spends ~12 us in dependent HBM round trips (kernel arguments -> own state ->
+// cell table -> neighbours); here those become LDS reads.  The host launches it for the stretch of
+// steps up to the next re-sort / phase update / caller boundary (stepMany).  Same device functions,
+// same order of operations as k_state + k_force: bit-identical results.
+template <bool PAYLOAD, bool FASTOK, int L>
+__global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict__ params, float4 *__restrict__ pr,
+                                                   float2 *__restrict__ vel, const float *__restrict__ phase,
+                                                   const int *__restrict__ dead, float *__restrict__ absA,
+                                                   float *__restrict__ absR, const uint32_t *__restrict__ orig,
+                                                   const uint32_t *__restrict__ cellSAll, uint32_t n, float dt,
+                                                   float time0, int nsteps, int lightWave) {
+  constexpr int CAP = 1024 / L;
+  __shared__ float4 sPr[2][CAP];
+  __shared__ float2 sVel[2][CAP];
+  const PbDevParams &P = params[blockIdx.x];
+  const uint32_t l = threadIdx.x / L, sub = threadIdx.x % L;
+  const bool active = l < n;
+  const uint32_t base = blockIdx.x * n;
+  const uint32_t s = base + (active ? l : 0u);
+  const uint32_t *__restrict__ cellS = cellSAll + (size_t)blockIdx.x * (P.numCells + 1u);
+
+  float4 me = pr[s];
+  float2 v = vel[s];
+  const float ph = phase[s];
+  const int dd = dead[s];
+  float fa = absA[s], fr = absR[s];
+  bool selfPayload = false;
+  if (PAYLOAD) selfPayload = (orig[s] == P.nCells - 1u);
+  const float att1 = selfPayload ? P.attractionFactor : 1.0f;
+
+  float t = time0;
+  // radius actuation + integration of the first step (k_state)
+  if (lightWave && t >= 0) me.z = pbActuate(P, me.z, ph, dd, fa, fr, t, dt);
+  pbIntegrate(P, me.x, me.y, v.x, v.y, me.z, dt);
+  if (active && sub == 0) {
+    sPr[0][l] = me;
+    sVel[0][l] = v;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int k = 0; k < nsteps; k++) {
+    const float tNext = t + dt;
+    if (active) {
+      PbForce F;
+      F.fx = 0.0f;
+      F.fy = 0.0f;
+      F.fa = 0.0f;
+      F.fr = 0.0f * fr;  // impl.cuh:688
+      const float4 *prIn = sPr[cur];
+      const float2 *velIn = sVel[cur];
+      if (FASTOK && __all(pbLaneFastMathOk(me.x, me.y)))
+        pbSweep<PAYLOAD, true, true, L, 1>(P, prIn, velIn, cellS, base, l, sub, me, v, att1, F);
+      else
+        pbSweep<PAYLOAD, true, false, L, 1>(P, prIn, velIn, cellS, base, l, sub, me, v, att1, F);
+      pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
+      pbFrictionAndKick(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
+      fa = F.fa;
+      fr = F.fr;
+      if (k + 1 < nsteps) {  // the next step's radius actuation + integration
+        if (lightWave && tNext >= 0) me.z = pbActuate(P, me.z, ph, dd, fa, fr, tNext, dt);
+        pbIntegrate(P, me.x, me.y, v.x, v.y, me.z, dt);
+        if (sub == 0) {
+          sPr[cur ^ 1][l] = me;
+          sVel[cur ^ 1][l] = v;
+        }
+      }
+    }
+    t = tNext;
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (active && sub == 0) {
+    pr[s] = me;
+    vel[s] = v;
+    absA[s] = fa;
+    absR[s] = fr;
   }
 }
 
@@ -621,7 +729,8 @@ struct pbSim {
   bool resortEveryStep = false;
   bool payload = false, fastOk = false;
   int variant = 2;  // force kernel: 0 reference-shaped branches, 1 branch-free, 2 (default) + fast exact math
-  int lanesPerBot = 0;  // latency form: 0 automatic; 1 throughput form; 4 ILP form (4 neighbours side by side); 8 eight lanes per bot
+  int resident = 0;     // 0 automatic, 1 never, 2 whenever the simulation fits one workgroup (n <= 1024)
+  int lanesPerBot = 0;  // lanes per bot of the per-step force kernel: 0 automatic; 1 (throughput form), 2, 4, 8
   pbSimStats stats{};
 };
 
@@ -649,19 +758,23 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
   const bool payload = S->payload;
   // variant 0: reference-shaped branches; 1: branch-free; 2 (default): branch-free + fast exact math
   const int kind = S->variant == 0 ? 0 : (S->variant == 1 || !S->fastOk) ? 1 : 2;
-  // Small batches (under ~1 wave per SIMD) are bound by one wave's serial neighbour loop, not by
-  // VALU throughput.  Two latency forms: NB = 4 neighbours side by side (ILP), and for tiny batches
-  // additionally 8 lanes per bot.  Only the branch-free kernels have them.  form: 0 throughput,
-  // 1 ILP, 2 multi-lane.
+  // A per-step launch of a small or medium batch is bound by one wave's serial neighbour loop, not
+  // by VALU throughput, so bots get L = 8 or 4 lanes each while the chip has lanes to spare
+  // (measured on MI355X, one simulation on the bench lattice, us/step for L = 1/2/4/8:
+  //  10^4 bots 29/-/-/12, 6x10^4 31/25/21/24, 10^5 37/29/29/34, 2x10^5 39/45/48/58).
+  // Only the branch-free kernels have the multi-lane forms.
   int form = 0;
   if (kind != 0) {
-    if (S->lanesPerBot == 8 || (S->lanesPerBot == 0 && S->total <= 4096u)) form = 2;
-    else if (S->lanesPerBot == 4 || (S->lanesPerBot == 0 && S->total <= 131072u)) form = 1;
+    const int want = S->lanesPerBot;
+    if (want == 8 || (want == 0 && S->total <= 49152u)) form = 8;
+    else if (want == 4 || (want == 0 && S->total <= 131072u)) form = 4;
+    else if (want == 2) form = 2;
   }
 #define PB_CASE(F, PL, K, FL, FA)                                                                        \
   if (fuse == F && payload == PL && kind == K) {                                                         \
-    if (FL && form == 2) return launchForceT<F, PL, FL, FA, (FL ? 8 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
-    if (FL && form == 1) return launchForceT<F, PL, FL, FA, 1, (FL ? 4 : 1)>(S, c, o, dt, tNext, doRadiusNext); \
+    if (FL && form == 8) return launchForceT<F, PL, FL, FA, (FL ? 8 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
+    if (FL && form == 4) return launchForceT<F, PL, FL, FA, (FL ? 4 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
+    if (FL && form == 2) return launchForceT<F, PL, FL, FA, (FL ? 2 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     return launchForceT<F, PL, FL, FA, 1, (FL ? PB_THROUGHPUT_NB : 1)>(S, c, o, dt, tNext, doRadiusNext);                            \
   }
   PB_CASE(true, true, 0, false, false)
@@ -677,6 +790,54 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
   PB_CASE(false, false, 1, true, false)
   PB_CASE(false, false, 2, true, true)
 #undef PB_CASE
+}
+
+// ---- resident form (k_resident) ----------------------------------------------------------------
+// lanes per bot for a simulation of n bots held by one 1024-lane workgroup (0: does not fit)
+inline int residentLanes(uint32_t n) { return n <= 128u ? 8 : n <= 256u ? 4 : n <= 512u ? 2 : n <= 1024u ? 1 : 0; }
+
+bool residentWanted(const pbSim *S) {
+  if (S->resident == 1 || S->variant == 0 || S->resortEveryStep || residentLanes(S->n) == 0) return false;
+  if (S->lanesPerBot != 0 && S->resident != 2) return false;  // an explicit per-step form was asked for
+  if (S->resident == 2) return true;
+  // automatic: cost model fitted to MI355X measurements (microseconds per timestep of the whole
+  // batch).  One CU per simulation costs ~6 + 0.033 n however many
+  // simulations there are (up to one per CU); a per-step launch costs a ~10 us dependent-latency
+  // floor plus a term in the TOTAL number of bots.  So the resident form wins for ensembles of
+  // many small simulations and for single simulations of ~100 bots, and loses for a lone
+  // simulation of a few hundred bots that per-step launches spread over many CUs.
+  const double n = S->n, total = S->total;
+  const double residentUs = (6.0 + 0.033 * n) * (S->nsims > 256u ? S->nsims / 256.0 : 1.0);
+  const double perStepUs = total <= 49152.0 ? 10.5 + total / 3500.0
+                           : total <= 131072.0 ? 14.0 + total / 6500.0 : 22.0 + total / 5500.0;
+  return residentUs < perStepUs;
+}
+
+template <bool PAYLOAD, bool FASTOK>
+void launchResidentT(pbSim *S, float dt, float t0, int m, int lightWave) {
+  const int c = S->cur;
+  const int L = residentLanes(S->n);
+  const dim3 grid(S->nsims), block(cdiv(S->n * (uint32_t)L, 64u) * 64u);
+#define PB_RES(LL)                                                                                      \
+  hipLaunchKernelGGL((k_resident<PAYLOAD, FASTOK, LL>), grid, block, 0, S->stream, S->dP, S->pr[c], S->vel[c], \
+                     S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c], S->cellS, S->n, dt, t0, m,   \
+                     lightWave)
+  if (L == 8) PB_RES(8);
+  else if (L == 4) PB_RES(4);
+  else if (L == 2) PB_RES(2);
+  else PB_RES(1);
+#undef PB_RES
+}
+
+void launchResident(pbSim *S, float dt, float t0, int m, int lightWave) {
+  const bool fast = S->variant == 2 && S->fastOk;
+  if (S->payload) {
+    if (fast) launchResidentT<true, true>(S, dt, t0, m, lightWave);
+    else launchResidentT<true, false>(S, dt, t0, m, lightWave);
+  } else {
+    if (fast) launchResidentT<false, true>(S, dt, t0, m, lightWave);
+    else launchResidentT<false, false>(S, dt, t0, m, lightWave);
+  }
 }
 
 int resort(pbSim *S) {
@@ -735,6 +896,7 @@ int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
   const float pui = S->host.phase_update_interval;
   const bool lightWave = (S->host.control == LIGHT_WAVE);
   bool ahead = false;  // true: radius+integration of the coming step are already applied
+  const bool resident = residentWanted(S);
   int k = 0;
   for (; k < nsteps; k++) {
     const float t = S->time;
@@ -743,6 +905,23 @@ int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
       if (lightWave && gate(t, pui, dt)) {
         const int rc = phaseUpdate(S);
         if (rc) return rc;
+      }
+      if (resident && S->haveCells && !gate(t, sortInterval, dt)) {
+        // whole steps up to (not including) the next one that needs the host: a re-sort, a phase
+        // update, the end of the run or of this call.  tt repeats the fp32 time accumulation.
+        int m = 1;
+        float tt = t + dt;
+        while (k + m < nsteps && !(tt > S->host.max_time) && !(lightWave && gate(tt, pui, dt)) &&
+               !gate(tt, sortInterval, dt)) {
+          m++;
+          tt += dt;
+        }
+        launchResident(S, dt, t, m, (int)lightWave);
+        S->time = tt;
+        S->stats.steps += m;
+        S->stats.resident_launches++;
+        k += m - 1;
+        continue;
       }
       const int c = S->cur;
       hipLaunchKernelGGL(k_state, gA, b, 0, S->stream, S->dP, S->pr[c], S->vel[c], S->phase[c], S->dead[c],
@@ -757,7 +936,8 @@ int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
     // Fuse the next step's radius+integration unless this is the last step of the batch or the
     // next step will not run.  A phase update due at the start of the next step only needs the
     // positions of THIS step's integration, which are final now, so it runs before the launch.
-    const bool fuse = (k + 1 < nsteps) && !(tNext > S->host.max_time);
+    // (resident form: never run ahead, so that the next step can start a resident stretch)
+    const bool fuse = !resident && (k + 1 < nsteps) && !(tNext > S->host.max_time);
     if (fuse && lightWave && gate(tNext, pui, dt)) {
       const int rc = phaseUpdate(S);
       if (rc) return rc;
@@ -887,6 +1067,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   }
   if (const char *v = getenv("PB_FORCE_VARIANT")) S->variant = atoi(v);  // A/B switches for benchmarking
   if (const char *v = getenv("PB_LANES_PER_BOT")) S->lanesPerBot = atoi(v);
+  if (const char *v = getenv("PB_RESIDENT")) S->resident = atoi(v);
   const size_t n = S->n, total = S->total, G1 = (size_t)S->hP[0].numCells + 1;
 #define PB_TRY_NEW(expr)                                             \
   do {                                                               \
@@ -1166,8 +1347,17 @@ int pbSimSetForceVariant(pbSim *S, int variant) {
 }
 
 int pbSimSetLanesPerBot(pbSim *S, int lanes) {
-  if (!S || !(lanes == 0 || lanes == 1 || lanes == 4 || lanes == 8)) return PB_ERR_ARG;
+  if (!S || !(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8)) return PB_ERR_ARG;
   S->lanesPerBot = lanes;
+  return PB_OK;
+}
+
+int pbSimSetResident(pbSim *S, int mode) {
+  if (!S || mode < 0 || mode > 2) {
+    g_lastError = "pbSimSetResident: mode must be 0 (automatic), 1 (never) or 2 (whenever it fits)";
+    return PB_ERR_ARG;
+  }
+  S->resident = mode;
   return PB_OK;
 }
 

@@ -40,15 +40,18 @@ def compare(osim, gsim, what):
     assert gsim.time == osim.time, (what, gsim.time, osim.time)
 
 
-def test_golden_reference_probe(pb, orc, golden_dir):
+@pytest.mark.parametrize("resident", [1, 2])
+def test_golden_reference_probe(pb, orc, golden_dir, resident):
     """Engine started from the reference's own initial placement reproduces the reference-probe
     position snapshots (tests/golden/ref_probe) bit for bit through a phase update (step 1200),
-    and at step 20000, i.e. after the re-sort at step 18000."""
+    and at step 20000, i.e. after the re-sort at step 18000 -- with one kernel per timestep
+    (resident=1) and with the multi-step resident kernel (resident=2)."""
     P = orc.default_params(nCells=300, nDead=0, seed=5555, light_x=-2.0, light_y=4.0, phase_std=0.0, max_time=1e9)
     g = lambda k: np.fromfile(os.path.join(golden_dir, "ref_probe", f"example_like_pos_step{k}.bin"),
                               dtype=np.float32).reshape(-1, 2)
     sp, keep = simparams_from_orc(P)
     sim = pb.Sim(sp, keepalive=keep)
+    sim.set_resident(resident)
     n = 300
     sim.set_state(pos=g(0), vel=np.zeros((n, 2), np.float32), rad=np.full(n, P.min_radius, np.float32),
                   phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
@@ -59,7 +62,11 @@ def test_golden_reference_probe(pb, orc, golden_dir):
         assert_bit_equal(sim.get_state()["pos"], g(k), f"golden step {k}")
     s = sim.stats()
     assert s["steps"] == 20000 and s["resorts"] == 2 and s["phase_updates"] == 17
-    assert s["fused_launches"] > 19900  # one kernel per step except at batch ends
+    if resident == 1:
+        assert s["fused_launches"] > 19900 and s["resident_launches"] == 0  # one kernel per step except at batch ends
+    else:
+        # one launch per stretch between host events: 12 calls, 16 phase updates and 1 re-sort inside them
+        assert s["fused_launches"] == 0 and 12 <= s["resident_launches"] <= 12 + 17 + 2
 
 
 @pytest.mark.parametrize("case", ["example", "noise", "payload", "circles", "rects", "shadow"])
@@ -285,7 +292,8 @@ def test_fast_math_disabled_for_out_of_domain_constants(pb, orc):
     compare(osim, gsim, "tiny attraction")
 
 
-def test_ensemble_batch_matches_individual_oracles(pb, orc):
+@pytest.mark.parametrize("resident", [1, 2])
+def test_ensemble_batch_matches_individual_oracles(pb, orc, resident):
     """pbSimCreateBatch: 12 simulations that differ in seed, light position, noise level, obstacles
     and dead sets, stepped by the same launches, each bit-identical to its own oracle run -- through
     the initial sort, two phase updates and a forced re-sort schedule."""
@@ -309,6 +317,7 @@ def test_ensemble_batch_matches_individual_oracles(pb, orc):
         keep.append(ka)
         osims.append(osim)
     ens = pb.Ensemble(members, keepalive=keep)
+    ens.set_resident(resident)
     for k, osim in enumerate(osims):
         ens.set_state_of(k, pos=osim.get("pos"), vel=osim.get("vel"), rad=osim.get("rad"),
                          phase=osim.get("phase"), dead=osim.get("dead"))
@@ -328,6 +337,7 @@ def test_ensemble_batch_matches_individual_oracles(pb, orc):
         assert np.abs(com[k] - ref).max() < 1e-9
     s = ens.stats()
     assert s["steps"] == 2450 and s["phase_updates"] == 3 and s["resorts"] >= 3
+    assert (s["resident_launches"] > 0) == (resident == 2)
 
 
 def test_ensemble_rejects_mismatched_members(pb, orc):
@@ -337,12 +347,12 @@ def test_ensemble_rejects_mismatched_members(pb, orc):
         pb.Ensemble([a, b], keepalive=[ka, kb])
 
 
-@pytest.mark.parametrize("lanes", [1, 4, 8])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8])
 @pytest.mark.parametrize("case", ["payload_obstacles", "wrap_walls"])
 def test_lanes_per_bot_forms_match_oracle(pb, orc, lanes, case):
-    """The throughput form (one bot per lane, one neighbour per trip) and the two latency forms of
-    the force kernel (4 neighbours side by side; 8 lanes per bot) add the same terms in the same
-    order: all bit-identical to the oracle, also at the grid's x-wrap where a stencil row splits
+    """The throughput form (one bot per lane) and the multi-lane forms of the per-step force kernel
+    (2, 4, 8 lanes per bot, ordered group sum) add the same terms in the same order: all
+    bit-identical to the oracle, also at the grid's x-wrap where a stencil row splits
     into two slot ranges."""
     rng = np.random.default_rng(5)
     if case == "payload_obstacles":
@@ -365,3 +375,66 @@ def test_lanes_per_bot_forms_match_oracle(pb, orc, lanes, case):
         gsim.step(k - step)
         step = k
         compare(osim, gsim, f"{case} lanes={lanes} step {k}")
+
+
+@pytest.mark.parametrize("n", [100, 130, 400, 900])
+@pytest.mark.parametrize("case", ["noise", "payload_obstacles", "wrap_walls"])
+def test_resident_form_matches_oracle(pb, orc, n, case):
+    """k_resident (one workgroup per simulation, state in registers/LDS, many timesteps per launch)
+    against the oracle, bit for bit, for every lanes-per-bot width it has (n = 100: 8 lanes,
+    130: 4, 400: 2, 900: 1), through phase updates, frequent re-sorts (sort_interval 0.37 s cuts
+    the launches into 37-step stretches) and call boundaries."""
+    rng = np.random.default_rng(n)
+    if case == "noise":
+        P = orc.default_params(nCells=n, nDead=0, seed=77 + n, phase_std=0.6, max_time=1e9, light_x=-3.0, light_y=2.0)
+        osim, gsim = make_pair(pb, orc, P)
+        dead = np.zeros(n, np.int32)
+        dead[rng.choice(n, n // 7, replace=False)] = 1
+        osim.set("dead", dead)
+        gsim.set_state(dead=dead)
+    elif case == "payload_obstacles":
+        P = orc.default_params(nCells=n, nDead=-1, seed=21, phase_std=0.6, max_time=1e9, light_x=-5.0, light_y=0.0,
+                               attractionFactor=0.3, massFactor=1.7, n_cir_obstacles=1, x_cir_obs=[3.9],
+                               y_cir_obs=[0.2], r_cir_obs=[0.5], nobstacles=1, x1obs=[5.5], x2obs=[5.7],
+                               y1obs=[-0.5], y2obs=[0.5])
+        osim, gsim = make_pair(pb, orc, P)
+    else:
+        P = orc.default_params(nCells=n, nDead=0, seed=9, phase_std=0.0, max_time=1e9, light_x=80.0, light_y=80.0)
+        osim, gsim = make_pair(pb, orc, P)
+        pos, vel, rad = jittered_blob(n, 0.16, rng, center=(61.0, 62.0))
+        vel += np.float32(0.3)
+        osim.set("pos", pos), osim.set("vel", vel), osim.set("rad", rad)
+        gsim.set_state(pos=pos, vel=vel, rad=rad)
+    gsim.set_resident(2)
+    step = 0
+    for k in (1, 3, 40, 1203, 2500):
+        osim.run(k - step, sort_interval=0.37)
+        assert gsim.step(k - step, sort_interval=0.37) == k - step
+        step = k
+        compare(osim, gsim, f"{case} n={n} step {k}")
+    s = gsim.stats()
+    assert s["steps"] == 2500 and s["resident_launches"] >= 2500 // 37 and s["fused_launches"] == 0
+
+
+def test_resident_respects_max_time_and_call_boundaries(pb, orc):
+    """The resident stretch ends where the reference's loop would: at max_time, at a phase update,
+    at a re-sort, or at the end of the call -- and a later call continues from there."""
+    P = orc.default_params(nCells=256, nDead=0, seed=3, phase_std=0.0, max_time=0.505)
+    osim, gsim = make_pair(pb, orc, P)
+    gsim.set_resident(2)
+    ran = 0
+    while not osim.update():
+        ran += 1
+    assert gsim.step(30) == 30 and gsim.step(100) == ran - 30 and ran < 130
+    compare(osim, gsim, "max_time")
+    assert gsim.step(10) == 0
+
+
+def test_resident_is_automatic_for_small_simulations_only(pb, orc):
+    """The automatic choice follows the measured cost model: a lone ~100-bot simulation runs
+    resident, a lone larger one is spread over many CUs by per-step launches."""
+    for n, expect in ((100, True), (2000, False)):
+        P = orc.default_params(nCells=n, nDead=0, seed=4, phase_std=0.0, max_time=1e9)
+        _, gsim = make_pair(pb, orc, P)
+        gsim.step(50)
+        assert (gsim.stats()["resident_launches"] > 0) == expect, n
