@@ -396,9 +396,9 @@ PB_DEV void pbPairEvalK(const PbContactK &P, const bool (&live)[K], float ax, fl
                         const float (&attraction)[K], const float (&slope)[K], VelFetch velB,
                         PbPairTerm (&out)[K]) {
   const float near1 = 0.0009f, near2 = 0.0019f, fmin_attr = 2.5f;
-  float nx[K], ny[K], dist[K], reach[K], tx[K], ty[K];
+  float nx[K], ny[K], dist[K], reach[K], tx[K], ty[K], gapv[K];
   bool contact[K];
-  bool anyContact = false;
+  unsigned long long waveContact = 0ull, waveBand = 0ull;
 #pragma unroll
   for (int k = 0; k < K; k++) {
     const float rx = bx[k] - ax, ry = by[k] - ay;
@@ -422,12 +422,27 @@ PB_DEV void pbPairEvalK(const PbContactK &P, const bool (&live)[K], float ax, fl
       farx = attraction[k] * nx[k] / g2;
       fary = attraction[k] * ny[k] / g2;
     }
-    const float band = gap < near1 ? fmin_attr : fmin_attr + slope[k] * (gap - near1);
-    tx[k] = gap < near2 ? band * nx[k] : farx;
-    ty[k] = gap < near2 ? band * ny[k] : fary;
-    anyContact = anyContact || (contact[k] && live[k]);
+    tx[k] = farx;
+    ty[k] = fary;
+    gapv[k] = gap;
+    // wave-uniform masks, built from ballots of the plain comparisons (a bool carried across the
+    // branches below costs two extra vector instructions per trip)
+    const unsigned long long mLive = __builtin_amdgcn_ballot_w64(live[k]);
+    const unsigned long long mContact = __builtin_amdgcn_ballot_w64(contact[k]);
+    waveContact |= mLive & mContact;
+    waveBand |= mLive & ~mContact & __builtin_amdgcn_ballot_w64(gap < near2);
   }
-  if (__builtin_amdgcn_ballot_w64(anyContact) != 0ull) {  // wave-uniform
+  // the two near bands (gap < 0.0019) are rare -- a pair crosses them in a few timesteps while it
+  // makes or breaks contact -- so their coefficient is only worked out when some lane needs it
+  if (waveBand != 0ull) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const float band = gapv[k] < near1 ? fmin_attr : fmin_attr + slope[k] * (gapv[k] - near1);
+      tx[k] = gapv[k] < near2 ? band * nx[k] : tx[k];
+      ty[k] = gapv[k] < near2 ? band * ny[k] : ty[k];
+    }
+  }
+  if (waveContact != 0ull) {
     float2 vb[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {

@@ -209,7 +209,34 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
     const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
     const uint32_t lo = cellS[row + ((si & 1) ? 0u : mx0)] - base;
     const uint32_t hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base;
-    if (FLAT) {
+    if (FLAT && NB == 1) {
+      // One neighbour per trip, the next one's posrad load already in flight.  Unrolled by two
+      // with the two registers swapping roles, so the prefetched value needs no copy at the
+      // back-edge; lanes whose range ends after the first half leave through the break.  One
+      // slot past the range is still inside the array (spare element) and is never evaluated.
+      auto one = [&](const float4 &q, uint32_t j) __attribute__((always_inline)) {
+        const bool live[1] = {j != s};
+        const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
+        const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
+        const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
+        PbPairTerm t[1];
+        pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
+                             [&](int) { return velIn[j]; }, t);
+        pbPairAdd(live[0], t[0], F);
+      };
+      if (lo < hi) {
+        float4 q0 = prIn[lo];
+        uint32_t j = lo;
+        for (;;) {
+          const float4 q1 = prIn[j + 1];
+          one(q0, j);
+          if (++j >= hi) break;
+          q0 = prIn[j + 1];
+          one(q1, j);
+          if (++j >= hi) break;
+        }
+      }
+    } else if (FLAT) {
       // NB neighbours per trip, evaluated side by side (independent dependency chains for the
       // scheduler to interleave) and then summed in slot order.  The next trip's posrad loads
       // are already in flight (software pipeline).  Out-of-range slots alias the lane's own
@@ -243,7 +270,9 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
         }
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-          const uint32_t i1 = j + NB + k < hi ? j + NB + k : s;
+          // NB == 1: plain j + 1, no clamp -- one slot past the range is still inside the array
+          // (spare element at the end) and is never evaluated
+          const uint32_t i1 = (NB == 1 || j + NB + k < hi) ? j + NB + k : s;
           q[k] = prIn[i1];
           if (PREVEL) vq[k] = velIn[i1];
         }
@@ -336,7 +365,7 @@ __global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict
                                                    const uint32_t *__restrict__ cellSAll, uint32_t n, float dt,
                                                    float time0, int nsteps, int lightWave) {
   constexpr int CAP = 1024 / L;
-  __shared__ float4 sPr[2][CAP];
+  __shared__ float4 sPr[2][CAP + 1];  // +1: the sweep prefetches one slot past a range
   __shared__ float2 sVel[2][CAP];
   const PbDevParams &P = params[blockIdx.x];
   const uint32_t l = threadIdx.x / L, sub = threadIdx.x % L;
@@ -1084,7 +1113,8 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   PB_TRY_NEW(hipMalloc((void **)&S->dP, sizeof(PbDevParams) * nsims));
   PB_TRY_NEW(hipMemcpyAsync(S->dP, S->hP.data(), sizeof(PbDevParams) * nsims, hipMemcpyHostToDevice, S->stream));
   for (int i = 0; i < 2; i++) {
-    PB_TRY_NEW(hipMalloc((void **)&S->pr[i], sizeof(float4) * total));
+    // one spare element: the neighbour sweep prefetches one slot past the range it is walking
+    PB_TRY_NEW(hipMalloc((void **)&S->pr[i], sizeof(float4) * (total + 1)));
     PB_TRY_NEW(hipMalloc((void **)&S->vel[i], sizeof(float2) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->phase[i], sizeof(float) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->dead[i], sizeof(int) * total));
@@ -1093,7 +1123,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     PB_TRY_NEW(hipMalloc((void **)&S->orig[i], sizeof(uint32_t) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->keys[i], sizeof(uint32_t) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->vals[i], sizeof(uint32_t) * total));
-    PB_TRY_NEW(hipMemsetAsync(S->pr[i], 0, sizeof(float4) * total, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->pr[i], 0, sizeof(float4) * (total + 1), S->stream));
     PB_TRY_NEW(hipMemsetAsync(S->vel[i], 0, sizeof(float2) * total, S->stream));
     PB_TRY_NEW(hipMemsetAsync(S->phase[i], 0, sizeof(float) * total, S->stream));
     PB_TRY_NEW(hipMemsetAsync(S->dead[i], 0, sizeof(int) * total, S->stream));
