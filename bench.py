@@ -257,6 +257,8 @@ def main():
                          "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                          "traffic_source": (f"profiles/latest_traffic.json ({tr['profile']}): {tr['method']}"
                                             if tr else None),
+                         "valu": ({k: tr[k] for k in ("valu_issue_share", "valu_insts_per_wave",
+                                                      "valu_lane_utilisation") if k in tr} if tr else None),
                          "kernel": "k_force<FUSE> (forces of step n + radius/integration of step n+1)",
                          "launches": launches, "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * n,

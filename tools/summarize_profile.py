@@ -88,8 +88,15 @@ def main():
             write = d.get("WRITE_SIZE", 0.0) * 1024
             if traffic_json and k.startswith("k_force<true"):
                 import json
+                valu = {}
+                if d.get("SQ_WAVE_CYCLES") and d.get("SQ_ACTIVE_INST_VALU"):
+                    valu["valu_issue_share"] = 4 * d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
+                if d.get("SQ_INSTS_VALU") and d.get("SQ_WAVES"):
+                    valu["valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
+                if d.get("SQ_THREAD_CYCLES_VALU") and d.get("SQ_ACTIVE_INST_VALU"):
+                    valu["valu_lane_utilisation"] = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"] / 64
                 with open(traffic_json, "w") as fh:
-                    json.dump({"kernel": k, "profile": os.path.basename(root), "fetch_bytes_per_launch": fetch,
+                    json.dump({**valu, "kernel": k, "profile": os.path.basename(root), "fetch_bytes_per_launch": fetch,
                                "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                                "avg_launch_us_profiled": avg_ns / 1e3,
                                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
