@@ -193,7 +193,14 @@ int pbSimSetResortEveryStep(pbSim *sim, int on);
 
 /* Force-kernel variant of a simulation: 0 reference-shaped branches, 1 branch-free, 2 branch-free
  * with the fast exact sqrt/division forms (default; falls back to 1 when the simulation's
- * constants are outside their proven domain).  All variants give bit-identical results. */
+ * constants are outside their proven domain).  Variants 0-2 give bit-identical results.
+ * 3 = STREAMLINED arithmetic (opt-in, NOT bit-identical): distance and unit vector from one
+ * reciprocal square root, 1/gap^2 from one reciprocal, |F_attr| from its coefficient, FMA
+ * contraction, a bot's contact terms added after its attraction terms.  About twice as fast;
+ * agrees with variants 0-2 to ~1e-7 relative per 10 steps except where a bot lands on the other
+ * side of one of the reference's force-law discontinuities (DESIGN.md "Streamlined").  It only
+ * replaces the throughput form (batches above 131072 bots, or lanes-per-bot forced to 1); smaller
+ * batches keep running the exact kernels. */
 int pbSimSetForceVariant(pbSim *sim, int variant);
 /* Lanes per bot in the per-step force kernel: 1 = throughput form (one bot per lane); 2, 4, 8 =
  * that many adjacent lanes share a bot's neighbour list and add the terms in list order (batches

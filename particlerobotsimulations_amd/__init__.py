@@ -163,6 +163,13 @@ class Sim:
         _capi.check(_capi.lib().pbSimSetState(self._h, _capi.np_ptr(pos), _capi.np_ptr(vel), _capi.np_ptr(rad),
                                               _capi.np_ptr(phase), _capi.np_ptr(dead)), "pbSimSetState")
 
+    def set_forces(self, absForce_a, absForce_r):
+        """Overwrite absForce_a / absForce_r (original bot order): the two arrays the next step's
+        radius actuation reads.  With set_state this restores a complete mid-run state."""
+        n = self.n
+        a, r = self._in(absForce_a, np.float32, n), self._in(absForce_r, np.float32, n)
+        _capi.check(_capi.lib().pbSimSetForcesOf(self._h, 0, _capi.np_ptr(a), _capi.np_ptr(r)), "pbSimSetForcesOf")
+
     def get_state(self):
         n = self.n
         out = {
@@ -222,6 +229,8 @@ class Sim:
         return {k: int(getattr(s, k)) for k, _ in pbSimStats._fields_}
 
     def set_force_variant(self, variant):
+        """0/1/2: exact kernels (bit-identical to the oracle; 2 is the default).  3: streamlined
+        arithmetic, opt-in, not bit-identical (include/particlebot_hip.h)."""
         _capi.check(_capi.lib().pbSimSetForceVariant(self._h, int(variant)))
 
     def set_lanes_per_bot(self, lanes):

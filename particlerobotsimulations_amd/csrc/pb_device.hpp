@@ -509,6 +509,44 @@ PB_DEV void pbPairFlat(const PbDevParams &P, bool live, float ax, float ay, floa
   pbPairAdd(live, pbPairEval<FAST>(P, live, ax, ay, avx, avy, ra, bx, by, rb, attraction, slope, velB), F);
 }
 
+// ---- streamlined pair force (force variant 3; NOT bit-identical, see DESIGN.md "Streamlined") ----
+// The same physics as collideSpheres (impl.cuh:541-594) in the algebraically streamlined form
+// SURVEY.md 8(d) describes: one reciprocal square root gives the distance and the unit vector
+// (v_rsq_f32, 1 ulp), 1/gap^2 is one v_rcp_f32 (1 ulp), a non-contact term's magnitude is its
+// coefficient (|n| = 1) instead of length(), products and sums may contract to FMAs, and the
+// caller adds a bot's contact terms after its attraction terms instead of interleaved.  Every
+// operation is within 1-2 ulp of the reference's, which is the class of difference the reference's
+// own CUDA build has against any restatement (__powf, nvcc's FMA contraction); the tests hold it to
+// BASELINE.json's 1e-5 relative tolerance over teacher-forced windows.
+struct PbGeomS {
+  float nx, ny, dist;
+};
+// unit vector and distance from a to b; d2 must be nonzero (the caller substitutes 1 for the self slot)
+PB_DEV PbGeomS pbGeomS(float rx, float ry, float d2) {
+  const float inv = __builtin_amdgcn_rsqf(d2);
+  PbGeomS g;
+  g.dist = d2 * inv;
+  g.nx = rx * inv;
+  g.ny = ry * inv;
+  return g;
+}
+// non-contact coefficient c >= 0: the term is c*n and its magnitude is c (impl.cuh:579-592)
+PB_DEV float pbFarCoefS(float attraction, float gap) { return attraction * __builtin_amdgcn_rcpf(gap * gap); }
+PB_DEV float pbBandCoefS(float attraction, float gap) {
+  const float near1 = 0.0009f, fmin_attr = 2.5f;
+  return gap < near1 ? fmin_attr : __builtin_fmaf(pbBandSlope(attraction), gap - near1, fmin_attr);
+}
+// contact term: spring + dashpot + shear (impl.cuh:553-573); returns its magnitude
+PB_DEV float pbContactS(const PbContactK &P, const PbGeomS &g, float reach, float rvx, float rvy, float &cx,
+                        float &cy) {
+  const float vn = __builtin_fmaf(rvx, g.nx, rvy * g.ny);
+  const float tvx = __builtin_fmaf(-vn, g.nx, rvx), tvy = __builtin_fmaf(-vn, g.ny, rvy);
+  const float ks = -P.spring * (reach - g.dist);
+  cx = __builtin_fmaf(P.shear, tvx, __builtin_fmaf(P.damping, rvx, ks * g.nx));
+  cy = __builtin_fmaf(P.shear, tvy, __builtin_fmaf(P.damping, rvy, ks * g.ny));
+  return __builtin_amdgcn_sqrtf(__builtin_fmaf(cx, cx, cy * cy));
+}
+
 // common tail of obstacle contacts (impl.cuh:711-726 and :781-797): spring term (sx,sy) along the
 // contact normal (dx,dy), dashpot and shear against the bot's own velocity
 PB_DEV void pbObstacleTail(const PbDevParams &P, float vx, float vy, float dx, float dy, float sx, float sy,

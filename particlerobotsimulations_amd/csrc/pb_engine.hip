@@ -214,26 +214,33 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
       // with the two registers swapping roles, so the prefetched value needs no copy at the
       // back-edge; lanes whose range ends after the first half leave through the break.  One
       // slot past the range is still inside the array (spare element) and is never evaluated.
-      auto one = [&](const float4 &q, uint32_t j) __attribute__((always_inline)) {
-        const bool live[1] = {j != s};
+      // The loop runs on 32-bit BYTE offsets from the array base: one add and one compare per
+      // trip, and the neighbour's velocity sits at half the offset.
+      const char *const prBytes = (const char *)&prIn[0];
+      const char *const velBytes = (const char *)&velIn[0];
+      const uint32_t selfOff = s * 16u;
+      auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
+      auto one = [&](const float4 &q, uint32_t off) __attribute__((always_inline)) {
+        const bool live[1] = {off != selfOff};
         const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
         const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
         const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
         PbPairTerm t[1];
         pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
-                             [&](int) { return velIn[j]; }, t);
+                             [&](int) { return *(const float2 *)(velBytes + (off >> 1)); }, t);
         pbPairAdd(live[0], t[0], F);
       };
       if (lo < hi) {
-        float4 q0 = prIn[lo];
-        uint32_t j = lo;
+        uint32_t off = lo * 16u;
+        const uint32_t end = hi * 16u;
+        float4 q0 = at(off);
         for (;;) {
-          const float4 q1 = prIn[j + 1];
-          one(q0, j);
-          if (++j >= hi) break;
-          q0 = prIn[j + 1];
-          one(q1, j);
-          if (++j >= hi) break;
+          const float4 q1 = at(off + 16u);
+          one(q0, off);
+          if ((off += 16u) >= end) break;
+          q0 = at(off + 16u);
+          one(q1, off);
+          if ((off += 16u) >= end) break;
         }
       }
     } else if (FLAT) {
@@ -348,6 +355,139 @@ __global__ __launch_bounds__(TILE, PB_FORCE_WAVES) void k_force(const PbDevParam
     absA[s] = F.fa;
     absR[s] = F.fr;
   }
+}
+
+// Streamlined force kernel (force variant 3): same inputs, outputs and fusion as k_force, pair
+// arithmetic from pbGeomS/pbFarCoefS/pbContactS.  Results are NOT bit-identical to the reference
+// restatement; they stay within 1e-5 relative of it over teacher-forced windows (DESIGN.md
+// "Streamlined").  Two passes per bot:
+//   1. all candidates: distance, unit vector, attraction coefficient; accumulate force and Sum|F_attr|;
+//      a candidate in contact only has its slot pushed onto the lane's list in LDS
+//   2. the lane's contacts (a handful): spring/dashpot/shear, |F|, accumulate force and Sum|F_rep|
+// so the contact arithmetic runs for ~8 trips per bot instead of for every trip in which ANY lane of
+// the wave is in contact (nearly all 50 in a dense blob).  One bot per lane; throughput form only.
+#ifndef PB_STREAM_CAP
+#define PB_STREAM_CAP 12
+#endif
+template <bool FUSE, bool PAYLOAD>
+__global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__restrict__ params,
+                                                       const float4 *__restrict__ prIn,
+                                                       const float2 *__restrict__ velIn, float4 *__restrict__ prOut,
+                                                       float2 *__restrict__ velOut, const float *__restrict__ phase,
+                                                       const int *__restrict__ dead, float *__restrict__ absA,
+                                                       float *__restrict__ absR, const uint32_t *__restrict__ orig,
+                                                       const uint32_t *__restrict__ cellSAll, uint32_t n, float dt,
+                                                       float timeNext, int doRadiusNext, uint32_t perXcd) {
+  __shared__ uint32_t contacts[PB_STREAM_CAP][TILE];  // column = lane: conflict-free
+  const PbDevParams &P = params[blockIdx.y];
+  const uint32_t tile = perXcd ? (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t l = tile * TILE + threadIdx.x;
+  if (l >= n) return;
+  const uint32_t s = blockIdx.y * n + l;
+  const uint32_t *__restrict__ cellS = cellSAll + (size_t)blockIdx.y * (P.numCells + 1u);
+
+  const float4 me = prIn[s];
+  float2 v = velIn[s];
+  bool selfPayload = false;
+  if (PAYLOAD) selfPayload = (orig[s] == P.nCells - 1u);
+  const float att1 = selfPayload ? P.attractionFactor : 1.0f;
+  const float attraction0 = P.attraction;
+  const PbContactK CK{P.spring, P.damping, P.shear};
+  const float near2 = 0.0019f;
+
+  float fx = 0.0f, fy = 0.0f, fa = 0.0f;
+  float fr = 0.0f * absR[s];  // impl.cuh:688
+  uint32_t cnt = 0;
+
+  auto contactOf = [&](uint32_t j, const float4 &q) __attribute__((always_inline)) {
+    const float rx = q.x - me.x, ry = q.y - me.y;
+    const PbGeomS g = pbGeomS(rx, ry, fmaxf(__builtin_fmaf(rx, rx, ry * ry), 1e-30f));
+    const float2 vb = velIn[j];
+    float cx, cy;
+    const float mag = pbContactS(CK, g, me.z + q.z, vb.x - v.x, vb.y - v.y, cx, cy);
+    fx += cx;
+    fy += cy;
+    fr += mag;
+  };
+  // No test for the bot's own slot: with d2 clamped away from zero the self pair has n = 0 and
+  // gap = -reach, so it lands on the contact list, where it evaluates to a zero force (n = 0,
+  // relative velocity 0).  (Two distinct bots at the same point, NaN in the reference, also give 0.)
+  auto one = [&](const float4 &q, uint32_t off) __attribute__((always_inline)) {
+    const float rx = q.x - me.x, ry = q.y - me.y;
+    const float d2 = fmaxf(__builtin_fmaf(rx, rx, ry * ry), 1e-30f);
+    const float inv = __builtin_amdgcn_rsqf(d2);                   // 1/dist
+    const float gap = __builtin_fmaf(d2, inv, -(me.z + q.z));      // dist - reach
+    const bool contact = gap < 0.0f;                               // dist < reach
+    const float A = PAYLOAD ? attraction0 * q.w * att1 : attraction0;
+    float coef = pbFarCoefS(A, gap);
+    // the two near bands are rare: wave-uniform branch on ballots of the plain comparisons
+    const unsigned long long mNear =
+        __builtin_amdgcn_ballot_w64(gap < near2) & ~__builtin_amdgcn_ballot_w64(contact);
+    if (mNear != 0ull) coef = gap < near2 ? pbBandCoefS(A, gap) : coef;
+    coef = contact ? 0.0f : coef;
+    const float ci = coef * inv;  // term = coef * n = (coef / dist) * r
+    fx = __builtin_fmaf(ci, rx, fx);
+    fy = __builtin_fmaf(ci, ry, fy);
+    fa += coef;
+    if (contact) {
+      if (cnt < (uint32_t)PB_STREAM_CAP) contacts[cnt][threadIdx.x] = off >> 4;
+      else contactOf(off >> 4, q);  // list full (pathological compression): evaluate in place
+      cnt++;
+    }
+  };
+
+  const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
+  const uint32_t GX = P.gridX;
+  const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
+  const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;
+  const int nseg = first < 5u ? 2 : 1;
+#pragma unroll 1
+  for (int si = 0; si < 10; si++) {
+    if ((si & 1) && nseg == 1) continue;
+    const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+    const uint32_t lo = cellS[row + ((si & 1) ? 0u : mx0)];
+    const uint32_t hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)];
+    if (lo < hi) {
+      // posrad loads run two neighbours ahead; three registers rotate roles so nothing is copied
+      // at the back-edge.  Up to two slots past the range are read (spare elements at the end of
+      // the array), never evaluated.  The loop runs on 32-bit BYTE offsets from the array base
+      // (one add and one compare per trip; the slot number is only rebuilt for a contact).
+      const char *const prBytes = (const char *)prIn;
+      auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
+      uint32_t off = lo * 16u;
+      const uint32_t end = hi * 16u;
+      float4 q0 = at(off), q1 = at(off + 16u);
+      for (;;) {
+        const float4 q2 = at(off + 32u);
+        one(q0, off);
+        if ((off += 16u) >= end) break;
+        q0 = at(off + 32u);
+        one(q1, off);
+        if ((off += 16u) >= end) break;
+        q1 = at(off + 32u);
+        one(q2, off);
+        if ((off += 16u) >= end) break;
+      }
+    }
+  }
+  const uint32_t listed = cnt < (uint32_t)PB_STREAM_CAP ? cnt : (uint32_t)PB_STREAM_CAP;
+  for (uint32_t k = 0; k < listed; k++) {
+    const uint32_t j = contacts[k][threadIdx.x];
+    contactOf(j, prIn[j]);
+  }
+
+  PbForce F{fx, fy, fa, fr};
+  pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
+  pbFrictionAndKick(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
+  float4 out = me;
+  if (FUSE) {
+    if (doRadiusNext) out.z = pbActuate(P, me.z, phase[s], dead[s], F.fa, F.fr, timeNext, dt);
+    pbIntegrate(P, out.x, out.y, v.x, v.y, out.z, dt);
+  }
+  prOut[s] = out;
+  velOut[s] = v;
+  absA[s] = F.fa;
+  absR[s] = F.fr;
 }
 
 // Resident form for small simulations: ONE workgroup per simulation keeps its bots in registers
@@ -785,6 +925,23 @@ void launchForceT(pbSim *S, int c, int o, float dt, float tNext, int doRadiusNex
 
 void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext) {
   const bool payload = S->payload;
+  if (S->variant == 3 && S->total < (1u << 28) - 4u &&  // (32-bit byte offsets into posrad)
+      (S->lanesPerBot == 1 || (S->lanesPerBot == 0 && S->total > 131072u))) {
+    // streamlined arithmetic: throughput form only (smaller batches use the exact forms below)
+    const uint32_t tiles = cdiv(S->n, TILE);
+    const uint32_t perXcd = tiles >= 64u ? cdiv(tiles, 8u) : 0u;
+    const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
+#define PB_STREAM(F, PL)                                                                                       \
+  hipLaunchKernelGGL((k_force_stream<F, PL>), grid, dim3(TILE), 0, S->stream, S->dP, S->pr[c], S->vel[c],     \
+                     S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c],        \
+                     S->cellS, S->n, dt, tNext, doRadiusNext, perXcd)
+    if (fuse && payload) PB_STREAM(true, true);
+    else if (fuse) PB_STREAM(true, false);
+    else if (payload) PB_STREAM(false, true);
+    else PB_STREAM(false, false);
+#undef PB_STREAM
+    return;
+  }
   // variant 0: reference-shaped branches; 1: branch-free; 2 (default): branch-free + fast exact math
   const int kind = S->variant == 0 ? 0 : (S->variant == 1 || !S->fastOk) ? 1 : 2;
   // A per-step launch of a small or medium batch is bound by one wave's serial neighbour loop, not
@@ -859,7 +1016,7 @@ void launchResidentT(pbSim *S, float dt, float t0, int m, int lightWave) {
 }
 
 void launchResident(pbSim *S, float dt, float t0, int m, int lightWave) {
-  const bool fast = S->variant == 2 && S->fastOk;
+  const bool fast = S->variant >= 2 && S->fastOk;
   if (S->payload) {
     if (fast) launchResidentT<true, true>(S, dt, t0, m, lightWave);
     else launchResidentT<true, false>(S, dt, t0, m, lightWave);
@@ -1087,6 +1244,12 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   S->nsims = (uint32_t)nsims;
   S->n = params[0].nCells;
   S->total = S->nsims * S->n;
+  if ((unsigned long long)S->nsims * S->n > (1ull << 28) - 8ull) {
+    // the neighbour sweeps address posrad with 32-bit byte offsets (16 bytes per bot)
+    g_lastError = "pbSimCreateBatch: more than 2^28 bots in one batch";
+    delete S;
+    return PB_ERR_ARG;
+  }
   S->hP.resize(nsims);
   S->payload = params[0].nDead == -1;
   S->fastOk = true;
@@ -1113,8 +1276,8 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   PB_TRY_NEW(hipMalloc((void **)&S->dP, sizeof(PbDevParams) * nsims));
   PB_TRY_NEW(hipMemcpyAsync(S->dP, S->hP.data(), sizeof(PbDevParams) * nsims, hipMemcpyHostToDevice, S->stream));
   for (int i = 0; i < 2; i++) {
-    // one spare element: the neighbour sweep prefetches one slot past the range it is walking
-    PB_TRY_NEW(hipMalloc((void **)&S->pr[i], sizeof(float4) * (total + 1)));
+    // spare elements: the neighbour sweeps prefetch up to three slots past the range they are walking
+    PB_TRY_NEW(hipMalloc((void **)&S->pr[i], sizeof(float4) * (total + 4)));
     PB_TRY_NEW(hipMalloc((void **)&S->vel[i], sizeof(float2) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->phase[i], sizeof(float) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->dead[i], sizeof(int) * total));
@@ -1123,7 +1286,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     PB_TRY_NEW(hipMalloc((void **)&S->orig[i], sizeof(uint32_t) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->keys[i], sizeof(uint32_t) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->vals[i], sizeof(uint32_t) * total));
-    PB_TRY_NEW(hipMemsetAsync(S->pr[i], 0, sizeof(float4) * (total + 1), S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->pr[i], 0, sizeof(float4) * (total + 4), S->stream));
     PB_TRY_NEW(hipMemsetAsync(S->vel[i], 0, sizeof(float2) * total, S->stream));
     PB_TRY_NEW(hipMemsetAsync(S->phase[i], 0, sizeof(float) * total, S->stream));
     PB_TRY_NEW(hipMemsetAsync(S->dead[i], 0, sizeof(int) * total, S->stream));
@@ -1371,7 +1534,7 @@ int pbSimGetStats(pbSim *S, pbSimStats *stats) {
 }
 
 int pbSimSetForceVariant(pbSim *S, int variant) {
-  if (!S || variant < 0 || variant > 2) return PB_ERR_ARG;
+  if (!S || variant < 0 || variant > 3) return PB_ERR_ARG;
   S->variant = variant;
   return PB_OK;
 }

@@ -52,9 +52,10 @@ def main():
         st = sims[v].get_state()
         same = all(np.array_equal(st[k].view(np.uint32), ref[k].view(np.uint32))
                    for k in ("pos", "vel", "rad", "absForce_a", "absForce_r"))
+        dev = np.abs(st["pos"].astype(np.float64) - ref["pos"]).max()
         t = np.array(times[v])
         print(f"variant {v}: us/step per round {np.round(t, 1).tolist()}  median {np.median(t):.1f}  min {t.min():.1f}  "
-              f"=> {n / np.median(t) * 1e6:.3e} particle-steps/s   bit-identical to variant {variants[0]}: {same}")
+              f"=> {n / np.median(t) * 1e6:.3e} particle-steps/s   bit-identical to variant {variants[0]}: {same}  max|dpos| {dev:.3g}")
 
 
 if __name__ == "__main__":
