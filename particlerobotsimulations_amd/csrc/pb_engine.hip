@@ -202,38 +202,59 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
     }
     return;
   }
-  // rolled on purpose: one copy of the pair loop in the binary (unrolling the five rows made ten)
+  if (FLAT && NB == 1) {
+    // One bot per lane, one neighbour per trip (the throughput form).
+    //  * The loop over the 10 segments is rolled (one copy of the pair loop in the binary) and
+    //    software-pipelined two deep: while segment si runs, the cell-table bounds of segment
+    //    si + 2 and the first posrad of segment si + 1 are in flight.  Loaded just in time they are
+    //    two dependent memory round trips per segment, ~20 per bot, that only other waves can hide
+    //    -- and at the start and the end of a launch there are none.
+    //  * Inside a segment the next neighbour's posrad is already in flight, the loop is unrolled
+    //    by two with the two registers swapping roles (no copy at the back-edge), and it runs on
+    //    32-bit BYTE offsets from the array base (one add and one compare per trip; the
+    //    neighbour's velocity sits at half the offset).  One slot past a range is still inside
+    //    the array (spare elements) and is never evaluated.
+    const char *const prBytes = (const char *)&prIn[0];
+    const char *const velBytes = (const char *)&velIn[0];
+    const uint32_t selfOff = s * 16u;
+    auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
+    auto one = [&](const float4 &q, uint32_t off) __attribute__((always_inline)) {
+      const bool live[1] = {off != selfOff};
+      const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
+      const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
+      const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
+      PbPairTerm t[1];
+      pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
+                           [&](int) { return *(const float2 *)(velBytes + (off >> 1)); }, t);
+      pbPairAdd(live[0], t[0], F);
+    };
+    // byte offsets [lo, hi) of segment si; empty beyond the last one and for the second range of a
+    // row away from the x-wrap
+    auto bounds = [&](int si, uint32_t &lo, uint32_t &hi) __attribute__((always_inline)) {
+      lo = hi = selfOff;
+      if (si < 10) {
+        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+        lo = (cellS[row + ((si & 1) ? 0u : mx0)] - base) * 16u;
+        hi = (cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base) * 16u;
+      }
+    };
+    // segment numbers advance by 2 (one range per grid row) except for a lane at the x-wrap, whose
+    // rows split into two ranges: per-lane stride, the wave runs until its last lane is done
+    const int stride = nseg == 1 ? 2 : 1;
+    uint32_t loA, hiA, loB, hiB;
+    bounds(0, loA, hiA);
+    bounds(stride, loB, hiB);
+    float4 qA = at(loA);
 #pragma unroll 1
-  for (int si = 0; si < 10; si++) {
-    if ((si & 1) && nseg == 1) continue;  // second range of a row only exists at the x-wrap
-    const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
-    const uint32_t lo = cellS[row + ((si & 1) ? 0u : mx0)] - base;
-    const uint32_t hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base;
-    if (FLAT && NB == 1) {
-      // One neighbour per trip, the next one's posrad load already in flight.  Unrolled by two
-      // with the two registers swapping roles, so the prefetched value needs no copy at the
-      // back-edge; lanes whose range ends after the first half leave through the break.  One
-      // slot past the range is still inside the array (spare element) and is never evaluated.
-      // The loop runs on 32-bit BYTE offsets from the array base: one add and one compare per
-      // trip, and the neighbour's velocity sits at half the offset.
-      const char *const prBytes = (const char *)&prIn[0];
-      const char *const velBytes = (const char *)&velIn[0];
-      const uint32_t selfOff = s * 16u;
-      auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
-      auto one = [&](const float4 &q, uint32_t off) __attribute__((always_inline)) {
-        const bool live[1] = {off != selfOff};
-        const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
-        const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
-        const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
-        PbPairTerm t[1];
-        pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
-                             [&](int) { return *(const float2 *)(velBytes + (off >> 1)); }, t);
-        pbPairAdd(live[0], t[0], F);
-      };
-      if (lo < hi) {
-        uint32_t off = lo * 16u;
-        const uint32_t end = hi * 16u;
-        float4 q0 = at(off);
+    for (int si = 0; si < 10; si += stride) {
+      const uint32_t lo = loA, end = hiA;
+      float4 q0 = qA;
+      loA = loB;
+      hiA = hiB;
+      qA = at(loA);                        // first posrad of the next segment
+      bounds(si + 2 * stride, loB, hiB);   // bounds of the one after
+      if (lo < end) {
+        uint32_t off = lo;
         for (;;) {
           const float4 q1 = at(off + 16u);
           one(q0, off);
@@ -243,7 +264,17 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
           if ((off += 16u) >= end) break;
         }
       }
-    } else if (FLAT) {
+    }
+    return;
+  }
+  // rolled on purpose: one copy of the pair loop in the binary (unrolling the five rows made ten)
+#pragma unroll 1
+  for (int si = 0; si < 10; si++) {
+    if ((si & 1) && nseg == 1) continue;  // second range of a row only exists at the x-wrap
+    const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+    const uint32_t lo = cellS[row + ((si & 1) ? 0u : mx0)] - base;
+    const uint32_t hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base;
+    if (FLAT) {
       // NB neighbours per trip, evaluated side by side (independent dependency chains for the
       // scheduler to interleave) and then summed in slot order.  The next trip's posrad loads
       // are already in flight (software pipeline).  Out-of-range slots alias the lane's own
@@ -441,22 +472,38 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
   const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
   const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;
   const int nseg = first < 5u ? 2 : 1;
+  // Segment loop rolled and software-pipelined two deep, as in pbSweep: while segment si runs, the
+  // cell-table bounds of segment si + 2 and the first two posrad of segment si + 1 are in flight.
+  // Inside a segment posrad loads run two neighbours ahead, three registers rotating roles; the
+  // loop runs on 32-bit byte offsets.  Up to two slots past a range are read (spare elements at
+  // the end of the array), never evaluated.
+  const char *const prBytes = (const char *)prIn;
+  auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
+  const uint32_t selfOff = s * 16u;
+  auto bounds = [&](int si, uint32_t &lo, uint32_t &hi) __attribute__((always_inline)) {
+    lo = hi = selfOff;
+    if (si < 10) {
+      const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+      lo = cellS[row + ((si & 1) ? 0u : mx0)] * 16u;
+      hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)] * 16u;
+    }
+  };
+  const int stride = nseg == 1 ? 2 : 1;  // per lane: two ranges per grid row only at the x-wrap
+  uint32_t loA, hiA, loB, hiB;
+  bounds(0, loA, hiA);
+  bounds(stride, loB, hiB);
+  float4 qA0 = at(loA), qA1 = at(loA + 16u);
 #pragma unroll 1
-  for (int si = 0; si < 10; si++) {
-    if ((si & 1) && nseg == 1) continue;
-    const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
-    const uint32_t lo = cellS[row + ((si & 1) ? 0u : mx0)];
-    const uint32_t hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)];
-    if (lo < hi) {
-      // posrad loads run two neighbours ahead; three registers rotate roles so nothing is copied
-      // at the back-edge.  Up to two slots past the range are read (spare elements at the end of
-      // the array), never evaluated.  The loop runs on 32-bit BYTE offsets from the array base
-      // (one add and one compare per trip; the slot number is only rebuilt for a contact).
-      const char *const prBytes = (const char *)prIn;
-      auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
-      uint32_t off = lo * 16u;
-      const uint32_t end = hi * 16u;
-      float4 q0 = at(off), q1 = at(off + 16u);
+  for (int si = 0; si < 10; si += stride) {
+    const uint32_t lo = loA, end = hiA;
+    float4 q0 = qA0, q1 = qA1;
+    loA = loB;
+    hiA = hiB;
+    qA0 = at(loA);
+    qA1 = at(loA + 16u);
+    bounds(si + 2 * stride, loB, hiB);
+    if (lo < end) {
+      uint32_t off = lo;
       for (;;) {
         const float4 q2 = at(off + 32u);
         one(q0, off);
@@ -1227,9 +1274,10 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
       return PB_ERR_ARG;
     }
   }
-  if ((uint64_t)params[0].nCells * (uint64_t)nsims > 0xFFFFFFF0ull ||
+  // (the neighbour sweeps address posrad with 32-bit BYTE offsets, 16 bytes per bot: 2^28 bots)
+  if ((uint64_t)params[0].nCells * (uint64_t)nsims > (1ull << 28) - 8ull ||
       (uint64_t)params[0].numCells * (uint64_t)nsims > 0xFFFFFFF0ull) {
-    g_lastError = "pbSimCreateBatch: batch too large for 32-bit slot / key indices";
+    g_lastError = "pbSimCreateBatch: batch too large (at most 2^28 bots and 2^32 cells in one batch)";
     return PB_ERR_ARG;
   }
   int count = 0;
@@ -1244,12 +1292,6 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   S->nsims = (uint32_t)nsims;
   S->n = params[0].nCells;
   S->total = S->nsims * S->n;
-  if ((unsigned long long)S->nsims * S->n > (1ull << 28) - 8ull) {
-    // the neighbour sweeps address posrad with 32-bit byte offsets (16 bytes per bot)
-    g_lastError = "pbSimCreateBatch: more than 2^28 bots in one batch";
-    delete S;
-    return PB_ERR_ARG;
-  }
   S->hP.resize(nsims);
   S->payload = params[0].nDead == -1;
   S->fastOk = true;
