@@ -126,6 +126,15 @@ class Particlebot {
    * bit-identically.  Both return false on I/O or format errors. */
   bool saveCheckpoint(FILE *fp);
   bool loadCheckpoint(FILE *fp);
+  /* Headless stand-in for the reference's display()/video path (main.cpp:354-470, colours from
+   * updateCol_k, particlebot_kernel_impl.cuh:401-443): writes a binary PPM (P6) of width x height
+   * pixels showing the square |x - centerX|, |y - centerY| <= halfExtent seen from above, x
+   * mirrored as the reference draws it.  Bots are discs of their current radius: dead bots black,
+   * live ones R = 30, G = 20 + 180 ((max_r - r)/(max_r - min_r))^2, B = 30 + 180
+   * sqrt((r - min_r)/(max_r - min_r)); obstacles grey, the light a yellow disc of lightRadius.
+   * (The display_shadow tint is not drawn.)  Returns false on I/O errors. */
+  bool writeFramePPM(const char *path, int width, int height, float centerX, float centerY, float halfExtent,
+                     float lightRadius = 0.25f);
   /* HostOnly engines follow an external clock */
   void setHostTime(float t) { time = t; }
 

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 
@@ -712,6 +713,63 @@ bool putv(FILE *fp, const T *p, size_t count) { return fwrite(p, sizeof(T), coun
 template <class T>
 bool getv(FILE *fp, T *p, size_t count) { return fread(p, sizeof(T), count, fp) == count; }
 }  // namespace
+
+// ---- headless frame (stands in for display() + the OpenCV video writer) -------------------------
+
+bool Particlebot::writeFramePPM(const char *path, int width, int height, float centerX, float centerY,
+                                float halfExtent, float lightRadius) {
+  if (!path || width <= 0 || height <= 0 || !(halfExtent > 0)) return false;
+  pullState(true, false, true);
+  const int *deadNow = getDeadArray();
+  std::vector<unsigned char> img((size_t)width * height * 3, 245);
+  const float scale = 0.5f * (float)height / halfExtent;  // pixels per world unit
+  // world -> pixel: x mirrored (the reference translates by -x), y up
+  auto px = [&](float x) { return 0.5f * (float)width - (x - centerX) * scale; };
+  auto py = [&](float y) { return 0.5f * (float)height - (y - centerY) * scale; };
+  auto disc = [&](float x, float y, float r, unsigned char R, unsigned char G, unsigned char B) {
+    const float cx = px(x), cy = py(y), pr = r * scale;
+    const int x0 = std::max(0, (int)floorf(cx - pr)), x1 = std::min(width - 1, (int)ceilf(cx + pr));
+    const int y0 = std::max(0, (int)floorf(cy - pr)), y1 = std::min(height - 1, (int)ceilf(cy + pr));
+    for (int yy = y0; yy <= y1; yy++)
+      for (int xx = x0; xx <= x1; xx++) {
+        const float dx = (float)xx + 0.5f - cx, dy = (float)yy + 0.5f - cy;
+        if (dx * dx + dy * dy <= pr * pr) {
+          unsigned char *p = &img[((size_t)yy * width + xx) * 3];
+          p[0] = R, p[1] = G, p[2] = B;
+        }
+      }
+  };
+  for (int k = 0; k < params.nobstacles; k++) {  // rectangles
+    const float xa = px(params.x2obs[k]), xb = px(params.x1obs[k]);  // mirrored: x2 is left of x1
+    const float ya = py(params.y2obs[k]), yb = py(params.y1obs[k]);
+    for (int yy = std::max(0, (int)floorf(ya)); yy <= std::min(height - 1, (int)ceilf(yb)); yy++)
+      for (int xx = std::max(0, (int)floorf(xa)); xx <= std::min(width - 1, (int)ceilf(xb)); xx++) {
+        unsigned char *p = &img[((size_t)yy * width + xx) * 3];
+        p[0] = p[1] = p[2] = 110;
+      }
+  }
+  for (int k = 0; k < params.n_cir_obstacles; k++)
+    disc(params.x_cir_obs[k], params.y_cir_obs[k], params.r_cir_obs[k], 110, 110, 110);
+  disc(params.light_x, params.light_y, lightRadius, 250, 210, 40);
+  const float span = params.max_radius - params.min_radius;
+  for (uint i = 0; i < params.nCells; i++) {
+    const float r = hRad[i];
+    unsigned char R = 0, G = 0, B = 0;
+    if (!deadNow[i]) {  // updateCol_k, impl.cuh:413-417
+      const float g = span > 0 ? (params.max_radius - r) / span : 0.0f;
+      const float b = span > 0 ? (r - params.min_radius) / span : 0.0f;
+      R = 30;
+      G = (unsigned char)std::min(255.0f, std::max(0.0f, 20.0f + 180.0f * g * g));
+      B = (unsigned char)std::min(255.0f, std::max(0.0f, 30.0f + 180.0f * sqrtf(std::max(0.0f, b))));
+    }
+    disc(hPos[2 * i], hPos[2 * i + 1], r, R, G, B);
+  }
+  FILE *fp = fopen(path, "wb");
+  if (!fp) return false;
+  fprintf(fp, "P6\n%d %d\n255\n", width, height);
+  const bool ok = fwrite(img.data(), 1, img.size(), fp) == img.size();
+  return fclose(fp) == 0 && ok;
+}
 
 bool Particlebot::saveCheckpoint(FILE *fp) {
   if (engineKind != Engine::Fused || !fp) return false;

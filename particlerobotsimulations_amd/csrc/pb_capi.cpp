@@ -228,6 +228,17 @@ int pbHostLoadFromFile(void *hv, const char *path) {
   return 0;
 }
 
+// half <= 0 selects the reference's camera: centred on (camera_x, 0), half extent camera_y * tan(30 deg)
+int pbHostWriteFrame(void *hv, const char *path, int width, int height, float cx, float cy, float half) {
+  HostSim *h = (HostSim *)hv;
+  if (!(half > 0)) {
+    cx = h->cfg.camera_x;
+    cy = 0.0f;
+    half = h->cfg.camera_y * 0.57735027f;
+  }
+  return h->bot->writeFramePPM(path, width, height, cx, cy, half, h->cfg.light_radius) ? 0 : -1;
+}
+
 int pbHostSaveCheckpoint(void *hv, const char *path) {
   FILE *fp = fopen(path, "wb");
   if (!fp) return -1;

@@ -166,6 +166,15 @@ class HostSim:
         lib().pbHostDrawDead(self._h, out.ctypes.data_as(C.c_void_p))
         return out
 
+    def write_frame(self, path, size=800, center=(0.0, 0.0), half_extent=0.0):
+        """Binary PPM of the arena seen from above (Particlebot::writeFramePPM).  half_extent <= 0:
+        the reference's camera, centred on (camera_x, 0), half extent camera_y * tan(30 deg)."""
+        L = lib()
+        L.pbHostWriteFrame.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+        if L.pbHostWriteFrame(self._h, os.fsencode(path), int(size), int(size), center[0], center[1],
+                              half_extent) != 0:
+            raise OSError(f"writeFramePPM({path}) failed")
+
     def save_checkpoint(self, path):
         rc = lib().pbHostSaveCheckpoint(self._h, os.fsencode(path))
         if rc != 0:

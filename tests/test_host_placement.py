@@ -86,3 +86,38 @@ def test_square_lattice_placement(host):
     pos = h.get("pos")
     assert abs(pos.mean(0)).max() < 1e-4
     assert np.allclose(np.diff(pos[:100, 0]), 0.155, atol=1e-6) and np.all(pos[:100, 1] == pos[0, 1])
+
+
+def test_headless_frame(tmp_path):
+    """Particlebot::writeFramePPM (stand-in for the reference's display/video path): a P6 image in
+    which every bot is a disc of its radius in updateCol_k's colour, x mirrored as the reference
+    draws it, the light a yellow disc, dead bots black."""
+    from particlerobotsimulations_amd import host
+    sim = host.HostSim(os.path.join(ROOT, "examples", "example_dead_cells.cfg"), engine="host",
+                       time_to_dead="0")
+    sim.draw_dead()
+    path = str(tmp_path / "f.ppm")
+    size, half = 600, 4.0
+    cx, cy = 5.0, 0.0
+    sim.write_frame(path, size=size, center=(cx, cy), half_extent=half)
+    raw = open(path, "rb").read()
+    header = f"P6\n{size} {size}\n255\n".encode()
+    assert raw.startswith(header) and len(raw) == len(header) + size * size * 3
+    img = np.frombuffer(raw[len(header):], np.uint8).reshape(size, size, 3)
+    pos, rad, dead = sim.get("pos"), sim.get("rad"), sim.get("dead")
+    scale = 0.5 * size / half
+    hit_live = hit_dead = 0
+    for (x, y), r, d in zip(pos, rad, dead):
+        px, py = int(0.5 * size - (x - cx) * scale), int(0.5 * size - (y - cy) * scale)
+        if not (0 <= px < size and 0 <= py < size):
+            continue
+        c = img[py, px]
+        if d:
+            hit_dead += int((c == 0).all())
+        else:  # all radii are min_radius after reset: G = 20 + 180, B = 30
+            hit_live += int(tuple(c) == (30, 200, 30))
+    assert hit_dead == int(dead.sum()) == 20 and hit_live == len(rad) - 20
+    # bot area in pixels ~ sum(pi r^2) * scale^2 (bots touch but do not overlap after placement)
+    botpix = int(((img != 245).any(axis=2)).sum())
+    expect = float((np.pi * rad.astype(np.float64) ** 2).sum()) * scale * scale
+    assert 0.9 * expect <= botpix <= 1.15 * expect + np.pi * (0.25 * scale) ** 2
