@@ -218,14 +218,14 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
     const char *const velBytes = (const char *)&velIn[0];
     const uint32_t selfOff = s * 16u;
     auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
-    auto one = [&](const float4 &q, uint32_t off) __attribute__((always_inline)) {
+    auto vat = [&](uint32_t off) __attribute__((always_inline)) { return *(const float2 *)(velBytes + (off >> 1)); };
+    auto one = [&](const float4 &q, const float2 &vq, uint32_t off) __attribute__((always_inline)) {
       const bool live[1] = {off != selfOff};
       const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
       const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
       const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
       PbPairTerm t[1];
-      pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
-                           [&](int) { return *(const float2 *)(velBytes + (off >> 1)); }, t);
+      pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K, [&](int) { return vq; }, t);
       pbPairAdd(live[0], t[0], F);
     };
     // byte offsets [lo, hi) of segment si; empty beyond the last one and for the second range of a
@@ -245,22 +245,27 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
     bounds(0, loA, hiA);
     bounds(stride, loB, hiB);
     float4 qA = at(loA);
+    float2 vA = vat(loA);
 #pragma unroll 1
     for (int si = 0; si < 10; si += stride) {
       const uint32_t lo = loA, end = hiA;
       float4 q0 = qA;
+      float2 v0 = vA;
       loA = loB;
       hiA = hiB;
       qA = at(loA);                        // first posrad of the next segment
+      vA = vat(loA);
       bounds(si + 2 * stride, loB, hiB);   // bounds of the one after
       if (lo < end) {
         uint32_t off = lo;
         for (;;) {
           const float4 q1 = at(off + 16u);
-          one(q0, off);
+          const float2 v1 = vat(off + 16u);
+          one(q0, v0, off);
           if ((off += 16u) >= end) break;
           q0 = at(off + 16u);
-          one(q1, off);
+          v0 = vat(off + 16u);
+          one(q1, v1, off);
           if ((off += 16u) >= end) break;
         }
       }
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict
                                                    float time0, int nsteps, int lightWave) {
   constexpr int CAP = 1024 / L;
   __shared__ float4 sPr[2][CAP + 1];  // +1: the sweep prefetches one slot past a range
-  __shared__ float2 sVel[2][CAP];
+  __shared__ float2 sVel[2][CAP + 1];
   const PbDevParams &P = params[blockIdx.x];
   const uint32_t l = threadIdx.x / L, sub = threadIdx.x % L;
   const bool active = l < n;
@@ -1320,7 +1325,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   for (int i = 0; i < 2; i++) {
     // spare elements: the neighbour sweeps prefetch up to three slots past the range they are walking
     PB_TRY_NEW(hipMalloc((void **)&S->pr[i], sizeof(float4) * (total + 4)));
-    PB_TRY_NEW(hipMalloc((void **)&S->vel[i], sizeof(float2) * total));
+    PB_TRY_NEW(hipMalloc((void **)&S->vel[i], sizeof(float2) * (total + 4)));
     PB_TRY_NEW(hipMalloc((void **)&S->phase[i], sizeof(float) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->dead[i], sizeof(int) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->absA[i], sizeof(float) * total));
@@ -1329,7 +1334,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     PB_TRY_NEW(hipMalloc((void **)&S->keys[i], sizeof(uint32_t) * total));
     PB_TRY_NEW(hipMalloc((void **)&S->vals[i], sizeof(uint32_t) * total));
     PB_TRY_NEW(hipMemsetAsync(S->pr[i], 0, sizeof(float4) * (total + 4), S->stream));
-    PB_TRY_NEW(hipMemsetAsync(S->vel[i], 0, sizeof(float2) * total, S->stream));
+    PB_TRY_NEW(hipMemsetAsync(S->vel[i], 0, sizeof(float2) * (total + 4), S->stream));
     PB_TRY_NEW(hipMemsetAsync(S->phase[i], 0, sizeof(float) * total, S->stream));
     PB_TRY_NEW(hipMemsetAsync(S->dead[i], 0, sizeof(int) * total, S->stream));
     PB_TRY_NEW(hipMemsetAsync(S->absA[i], 0, sizeof(float) * total, S->stream));
