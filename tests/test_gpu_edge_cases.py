@@ -1,0 +1,138 @@
+"""Edge cases of the fused engine against the oracle, bit for bit: the smallest simulations, sizes
+around wave / workgroup / resident-capacity boundaries, every bot dead, full obstacle tables, bots
+pushed into the walls, everything in one cell, and every kernel form (per-step 1/2/4/8 lanes per
+bot, resident) for each."""
+import numpy as np
+import pytest
+
+from helpers import assert_bit_equal, jittered_blob, simparams_from_orc
+
+pytestmark = pytest.mark.gpu
+
+STATE_KEYS = ("pos", "vel", "rad", "phase", "absForce_a", "absForce_r")
+
+
+@pytest.fixture(scope="module")
+def pb():
+    import particlerobotsimulations_amd as pb
+    pb.legacy.cudaInit(0, None)
+    return pb
+
+
+def pair_with_state(pb, orc, P, pos, vel, rad, dead=None, wall_half=0.0):
+    n = P.nCells
+    osim = orc.Sim(P, reset=False)  # no placement: state given explicitly
+    sp, keep = simparams_from_orc(P)
+    gsim = pb.Sim(sp, wall_half=wall_half, keepalive=keep)
+    phase = np.zeros(n, np.float32)
+    dead = np.zeros(n, np.int32) if dead is None else dead
+    for name, a in (("pos", pos), ("vel", vel), ("rad", rad), ("phase", phase), ("dead", dead)):
+        osim.set(name, a)
+    gsim.set_state(pos=pos, vel=vel, rad=rad, phase=phase, dead=dead)
+    return osim, gsim
+
+
+def compare(osim, gsim, what):
+    st = gsim.get_state()
+    for k in STATE_KEYS:
+        assert_bit_equal(st[k], osim.get(k), f"{what}: {k}")
+
+
+FORMS = [("auto", None, 0), ("lanes1", 1, 1), ("lanes2", 2, 1), ("lanes4", 4, 1), ("lanes8", 8, 1), ("resident", None, 2)]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1023, 1024, 1025])
+def test_sizes_around_boundaries(pb, orc, n):
+    """n = 1 (no neighbour at all) up to one past the resident kernel's capacity, in every form."""
+    rng = np.random.default_rng(1000 + n)
+    pos, vel, rad = jittered_blob(n, 0.16, rng, center=(3.0, -2.0))
+    for name, lanes, resident in FORMS:
+        if resident == 2 and n > 1024:
+            continue
+        P = orc.default_params(nCells=n, nDead=0, seed=5, phase_std=0.4, max_time=1e9, light_x=-4.0, light_y=1.0)
+        osim, gsim = pair_with_state(pb, orc, P, pos, vel, rad)
+        if lanes is not None:
+            gsim.set_lanes_per_bot(lanes)
+        gsim.set_resident(resident)
+        step = 0
+        for k in (1, 2, 60, 1205):
+            osim.run(k - step, sort_interval=0.5)
+            assert gsim.step(k - step, sort_interval=0.5) == k - step
+            step = k
+            compare(osim, gsim, f"n={n} {name} step {k}")
+
+
+def test_all_dead_and_none_dead(pb, orc):
+    n = 400
+    rng = np.random.default_rng(7)
+    pos, vel, rad = jittered_blob(n, 0.16, rng, center=(5.0, 0.0))
+    for dead in (np.ones(n, np.int32), np.zeros(n, np.int32)):
+        P = orc.default_params(nCells=n, nDead=0, seed=5, phase_std=0.0, max_time=1e9)
+        osim, gsim = pair_with_state(pb, orc, P, pos, vel, rad, dead=dead)
+        osim.run(300)
+        gsim.step(300)
+        compare(osim, gsim, f"dead={int(dead[0])}")
+    # dead bots never actuate: radii unchanged
+    assert_bit_equal(gsim.get_state()["rad"] if dead[0] else rad, rad, "radii")
+
+
+def test_full_obstacle_tables(pb, orc):
+    """10 circular + 10 rectangular obstacles (the tables' capacity), bots started on top of them."""
+    n = 900
+    rng = np.random.default_rng(11)
+    pos, vel, rad = jittered_blob(n, 0.17, rng, center=(4.0, 0.0))
+    ang = np.linspace(0, 2 * np.pi, 10, endpoint=False)
+    P = orc.default_params(nCells=n, nDead=0, seed=5, phase_std=0.0, max_time=1e9, light_x=-5.0, light_y=0.0,
+                           n_cir_obstacles=10, x_cir_obs=list(4.0 + 1.5 * np.cos(ang)),
+                           y_cir_obs=list(1.5 * np.sin(ang)), r_cir_obs=[0.2 + 0.03 * k for k in range(10)],
+                           nobstacles=10, x1obs=[2.0 + 0.4 * k for k in range(10)],
+                           x2obs=[2.15 + 0.4 * k for k in range(10)], y1obs=[-2.6 + 0.1 * k for k in range(10)],
+                           y2obs=[-2.2 + 0.1 * k for k in range(10)])
+    osim, gsim = pair_with_state(pb, orc, P, pos, vel, rad)
+    step = 0
+    for k in (1, 10, 400):
+        osim.run(k - step)
+        gsim.step(k - step)
+        step = k
+        compare(osim, gsim, f"obstacles step {k}")
+
+
+def test_bots_in_the_walls_and_one_cell(pb, orc):
+    """Bots beyond the wall clamp on all four sides (the integrator pulls them back and reflects the
+    velocity), and a pile of bots inside one grid cell (a 25-cell stencil with one crowded cell)."""
+    rng = np.random.default_rng(13)
+    n = 300
+    pos = np.empty((n, 2), np.float32)
+    pos[:60] = [63.99, 0.0] + rng.uniform(-0.3, 0.3, (60, 2))
+    pos[60:120] = [-63.99, 5.0] + rng.uniform(-0.3, 0.3, (60, 2))
+    pos[120:180] = [7.0, 63.99] + rng.uniform(-0.3, 0.3, (60, 2))
+    pos[180:240] = [-9.0, -63.99] + rng.uniform(-0.3, 0.3, (60, 2))
+    pos[240:] = [1.0, 1.0] + rng.uniform(-0.05, 0.05, (60, 2))  # one cell (cell size 0.235)
+    vel = (rng.standard_normal((n, 2)) * 0.5).astype(np.float32)
+    rad = rng.uniform(0.0775, 0.1175, n).astype(np.float32)
+    P = orc.default_params(nCells=n, nDead=0, seed=5, phase_std=0.0, max_time=1e9, light_x=0.0, light_y=0.0)
+    for resident in (1, 2):
+        osim, gsim = pair_with_state(pb, orc, P, pos.astype(np.float32), vel, rad)
+        gsim.set_resident(resident)
+        step = 0
+        for k in (1, 5, 200):
+            osim.run(k - step, sort_interval=0.3)
+            gsim.step(k - step, sort_interval=0.3)
+            step = k
+            compare(osim, gsim, f"walls resident={resident} step {k}")
+    assert np.isfinite(gsim.get_state()["pos"]).all()
+
+
+def test_zero_steps_and_repeated_calls(pb, orc):
+    """step(0) is a no-op; 1-step calls equal one batched call (also checked elsewhere for 1000 bots)."""
+    n = 200
+    rng = np.random.default_rng(17)
+    pos, vel, rad = jittered_blob(n, 0.16, rng, center=(5.0, 0.0))
+    P = orc.default_params(nCells=n, nDead=0, seed=5, phase_std=0.0, max_time=1e9)
+    osim, gsim = pair_with_state(pb, orc, P, pos, vel, rad)
+    assert gsim.step(0) == 0
+    compare(osim, gsim, "after step(0)")
+    for _ in range(25):
+        assert gsim.step(1) == 1
+    osim.run(25)
+    compare(osim, gsim, "25 single steps")

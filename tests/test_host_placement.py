@@ -121,3 +121,16 @@ def test_headless_frame(tmp_path):
     botpix = int(((img != 245).any(axis=2)).sum())
     expect = float((np.pi * rad.astype(np.float64) ** 2).sum()) * scale * scale
     assert 0.9 * expect <= botpix <= 1.15 * expect + np.pi * (0.25 * scale) ** 2
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7])
+def test_tiny_placements_match_oracle(host, orc, n):
+    """The first bots are special-cased by the reference (seed bot at (5,0), bot 1 beside it, bot 2
+    perpendicular to that pair, particlebot.cpp:612-660): the smallest blobs, bit for bit."""
+    path = os.path.join(ROOT, "examples", "example.cfg")
+    h = host.HostSim(path, engine="host", nCells=str(n))
+    P = orc.load_cfg(path)
+    P.nCells = n
+    o = orc.Sim(P)
+    for k in ("pos", "vel", "rad", "phase"):
+        assert_bit_equal(h.get(k), o.get(k), f"n={n} {k}")
