@@ -310,7 +310,15 @@ def main():
             out["streamlined"] = streamlined_leg(pb, n, args.pitch, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.pitch)
-        print(json.dumps(out))
+        # the ONE JSON line goes last: push out whatever C libraries (RCCL's version banner) still hold
+        # in stdio buffers first
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
