@@ -121,3 +121,55 @@ def test_private_generator_equals_glibc_rand(host):
         want = [libc.rand() for _ in range(5000)]
         got = host.libc_rand_draws(seed, 5000).tolist()
         assert got == want, seed
+
+
+KEYS = ["camera_y", "camera_x", "nobstacles", "x1obs", "x2obs", "y1obs", "y2obs", "n_cir_obstacles", "x_cir_obs",
+        "y_cir_obs", "r_cir_obs", "min_radius", "max_radius", "centroid_int", "centroid_radius", "centroid_steps",
+        "radFactor", "massFactor", "frictionFactor", "attractionFactor", "dump_interval", "sort_interval",
+        "testing", "friction", "spring", "damping", "shear", "constraint", "constrained_contraction",
+        "constraint_contraction", "attraction", "boundaryDamping", "gravity", "nCells", "nDead", "time_to_dead",
+        "max_time", "seed", "light_radius", "light_x", "light_y", "timestep", "light_shadow", "csv_filename",
+        "video_filename", "rise_period", "phase_std", "display_shadow", "phase_update_interval", "Nx", "config",
+        "DISPLAY_INTERVAL", "VIDEO_INTERVAL"]
+
+
+def test_loader_fuzz_against_oracle(host, orc, tmp_path):
+    """Randomised files: known keys, truncated / extended / re-cased keys (the prefix matching makes
+    those interesting), short lines, comments, numeric and junk values, obstacle lists of random
+    length.  The product's loader and the oracle's must resolve every file to the same parameters."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    def mutate(key, how, tail):
+        if how == 0:
+            return key
+        if how == 1:
+            return key + tail                      # longer: still matches on the prefix
+        if how == 2:
+            return key[:max(1, len(key) - 1)]      # one character short: usually no match
+        if how == 3:
+            return key.upper()
+        return tail + key
+
+    number = st.one_of(st.integers(-5, 2000).map(str),
+                       st.floats(-50, 50, allow_nan=False, width=32).map(lambda f: f"{f:.6g}"),
+                       st.sampled_from(["", "abc", "1e3", "0x10", "  7", "3.5.1", "-", "1 2 3", "0.25 0.5 0.75 1 2"]))
+    line_pair = st.tuples(st.sampled_from(KEYS), st.integers(0, 4), st.sampled_from(["_x", "2", "zz", "#"]), number)
+    filler = st.sampled_from(["# comment", "", "ab", "xyz", "    "])
+
+    @settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+    @given(st.lists(st.one_of(line_pair, filler), min_size=0, max_size=40))
+    def run(items):
+        lines = []
+        for it in items:
+            if isinstance(it, tuple):
+                key, how, tail, value = it
+                lines += [mutate(key, how, tail), value]
+            else:
+                lines.append(it)
+        cfg = tmp_path / "fuzz.cfg"
+        cfg.write_text("\n".join(lines) + "\n")
+        flat = host.load_config(str(cfg))
+        P = orc.load_cfg(str(cfg))
+        assert same(flat, P) == [], "\n".join(lines)
+
+    run()
