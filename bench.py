@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-survey-literal", action="store_true")
     ap.add_argument("--no-streamlined", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the cpu_baseline sample")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path")
     args = ap.parse_args()
@@ -309,7 +310,7 @@ def main():
         if world == 1 and not args.no_streamlined:
             out["streamlined"] = streamlined_leg(pb, n, args.pitch, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, args.pitch)
+            out["cpu_baseline"] = cpu_baseline(n, args.pitch, args.cpu_seconds)
         # the ONE JSON line goes last: push out whatever C libraries (RCCL's version banner) still hold
         # in stdio buffers first
         sys.stdout.flush()
