@@ -51,13 +51,21 @@ struct PlacementGrid {
     head[c] = bot;
   }
   // any listed bot within `limit` of (x,y) in the 3x3 cells around it?
+  // The decision is the reference's `length(...) < limit` with its three powf calls; a double
+  // precision squared distance settles every pair that is not within 1e-5 (relative) of the limit
+  // -- hostLength is good to a few 1e-7 -- so the powf form only runs for pairs that (nearly) touch.
   bool crowded(float x, float y, const float *pos, double limit) const {
     const int xc = col(x), yc = row(y);
+    const double far2 = limit * limit * (1.0 + 2e-5), near2 = limit * limit * (1.0 - 2e-5);
     for (int xg = xc - 1; xg <= xc + 1; xg++)
       for (int yg = yc - 1; yg <= yc + 1; yg++) {
         if (xg < 0 || yg < 0 || xg >= (int)gx || yg >= (int)gy) continue;
-        for (int b = head[(size_t)xg * gy + yg]; b >= 0; b = next[b])
-          if (hostLength(x - pos[2 * b], y - pos[2 * b + 1]) < limit) return true;
+        for (int b = head[(size_t)xg * gy + yg]; b >= 0; b = next[b]) {
+          const float dx = x - pos[2 * b], dy = y - pos[2 * b + 1];
+          const double d2 = (double)dx * dx + (double)dy * dy;
+          if (d2 > far2) continue;
+          if (d2 < near2 || hostLength(dx, dy) < limit) return true;
+        }
       }
     return false;
   }
