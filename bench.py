@@ -294,13 +294,17 @@ def main():
                          "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                          "traffic_source": (f"profiles/latest_traffic.json ({tr['profile']}): {tr['method']}"
                                             if tr else None),
-                         "valu": ({k: tr[k] for k in ("valu_issue_share", "valu_insts_per_wave",
+                         "valu": ({k: tr[k] for k in ("valu_roofline_frac", "valu_time_us", "launch_us_unprofiled",
+                                                      "ns_simple", "ns_trans", "trans_per_wave",
+                                                      "valu_issue_share", "valu_insts_per_wave",
                                                       "valu_lane_utilisation") if k in tr} if tr else None),
                          "kernel": "k_force<FUSE> (forces of step n + radius/integration of step n+1)",
                          "launches": launches, "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * n,
                          "note": "the kernel is VALU-bound, not HBM-bound: ~50 neighbour pairs per bot, each "
-                                 "with 4 IEEE divisions and 2 IEEE square roots (DESIGN.md section 5)"},
+                                 "with 4 IEEE divisions and 2 IEEE square roots (DESIGN.md section 5).  `valu` "
+                                 "prices its instruction stream (PMC counts) at the issue rates tools/valu_rate "
+                                 "measures at 8 waves/SIMD: valu_roofline_frac is that VALU time over the launch time"},
             "device_ms_timed_region": dev_ms,
             "summaries_time_comx_comy": summaries,
         }

@@ -16,7 +16,13 @@ run() { # name, rocprof flags...
 run trace --kernel-trace --stats
 run pmc_sq --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
+run pmc_sq3 --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU
 run pmc_fetch --pmc FETCH_SIZE
 run pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+# VALU issue-rate microbenchmark (the yardstick for the force kernel's instruction mix), un-profiled
+[ -x tools/valu_rate ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/valu_rate.hip -o tools/valu_rate
+tools/valu_rate > "$OUT/valu_rate.txt" 2>&1
+# the same command un-profiled: kernel time at un-profiled clocks
+python3 bench.py $ARGS 2>/dev/null | tail -1 > "$OUT/bench_unprofiled.json"
 python3 tools/summarize_profile.py "$OUT" "$OUT/traffic.json" > "$OUT/summary.md" 2>"$OUT/summarize.err"
 cat "$OUT/summary.md"

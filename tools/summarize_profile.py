@@ -45,6 +45,29 @@ def pmc(root, sub):
     return out
 
 
+def valu_roofline(root, d, avg_ns_profiled, simds=1024):
+    """Fraction of the launch the SIMDs would need just to ISSUE the kernel's VALU instructions at the
+    rates tools/valu_rate measures at 8 waves per SIMD (simple fp32 ops; v_rcp/v_sqrt/v_rsq), against
+    the un-profiled launch time of the same command (profiled runs clock lower)."""
+    import json
+    try:
+        rates = json.loads([l for l in open(os.path.join(root, "valu_rate.txt")) if l.startswith("{")][-1])
+        bench = json.load(open(os.path.join(root, "bench_unprofiled.json")))
+    except Exception:
+        return None
+    if not (d.get("SQ_INSTS_VALU") and d.get("SQ_WAVES")) or d.get("SQ_INSTS_VALU_TRANS_F32") is None:
+        return None
+    r = rates["ns_per_wave_instr"]
+    ns_simple = (r["fma"] + r["mul"] + r["cmp_sel_mix"]) / 3.0
+    ns_trans = (r["rcp"] + r["sqrt"] + r["rsq"]) / 3.0
+    valu, trans = d["SQ_INSTS_VALU"], d["SQ_INSTS_VALU_TRANS_F32"]
+    valu_ns = ((valu - trans) * ns_simple + trans * ns_trans) / simds
+    launch_us = bench["roofline"]["avg_launch_us"]
+    return {"valu_roofline_frac": valu_ns / 1e3 / launch_us, "valu_time_us": valu_ns / 1e3,
+            "launch_us_unprofiled": launch_us, "ns_simple": ns_simple, "ns_trans": ns_trans,
+            "trans_per_wave": trans / d["SQ_WAVES"], "valu_per_wave": valu / d["SQ_WAVES"]}
+
+
 def main():
     root = sys.argv[1]
     traffic_json = sys.argv[2] if len(sys.argv) > 2 else None
@@ -59,7 +82,7 @@ def main():
         print(f"| {k} | {len(v)} | {sum(v)/1e6:.3f} | {sum(v)/len(v)/1e3:.2f} | {min(v)/1e3:.2f} | {max(v)/1e3:.2f} | "
               f"{100*sum(v)/total:.1f} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} |")
     counters = defaultdict(dict)
-    for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    for sub in ("pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write"):
         for k, cs in pmc(root, sub).items():
             for c, vals in cs.items():
                 counters[k][c] = sum(vals) / len(vals)
@@ -83,6 +106,13 @@ def main():
                 print(f"- derived: VALU lane utilisation = "
                       f"{d['SQ_THREAD_CYCLES_VALU']/d['SQ_ACTIVE_INST_VALU']/64:.3f} "
                       f"(THREAD_CYCLES_VALU / (ACTIVE_INST_VALU x 64))")
+        vr = valu_roofline(root, d, avg_ns)
+        if vr:
+            print(f"- derived: VALU issue roofline = {vr['valu_roofline_frac']:.3f} of the un-profiled launch time "
+                  f"({vr['valu_time_us']:.1f} us of VALU issue at the microbenchmark's 8-waves/SIMD rates -- "
+                  f"{vr['ns_simple']:.3f} ns per simple, {vr['ns_trans']:.3f} ns per transcendental wave-instruction "
+                  f"per SIMD -- over {vr['launch_us_unprofiled']:.1f} us; {vr['trans_per_wave']:.0f} transcendentals "
+                  f"of {vr['valu_per_wave']:.0f} VALU instructions per wave)")
         if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
             fetch = 2.0 * d.get("FETCH_SIZE", 0.0) * 1024  # gfx950: reports half of wide coalesced reads
             write = d.get("WRITE_SIZE", 0.0) * 1024
@@ -95,6 +125,9 @@ def main():
                     valu["valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
                 if d.get("SQ_THREAD_CYCLES_VALU") and d.get("SQ_ACTIVE_INST_VALU"):
                     valu["valu_lane_utilisation"] = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"] / 64
+                if vr:
+                    valu.update({kk: vr[kk] for kk in ("valu_roofline_frac", "valu_time_us", "launch_us_unprofiled",
+                                                       "ns_simple", "ns_trans", "trans_per_wave")})
                 with open(traffic_json, "w") as fh:
                     json.dump({**valu, "kernel": k, "profile": os.path.basename(root), "fetch_bytes_per_launch": fetch,
                                "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
