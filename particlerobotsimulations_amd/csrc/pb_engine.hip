@@ -25,6 +25,12 @@
 //    arrays concatenated (slot = sim*n + local), sort keys = sim*numCells + cell hash, one dense
 //    cell table per simulation.  An ensemble of small blobs costs one launch per timestep, not one
 //    per simulation; a single arena is the nsims == 1 case.
+//  * Three shapes of the same arithmetic, chosen per batch (launchForce / residentWanted), all
+//    bit-identical: k_force with L = 1 (one bot per lane: throughput), k_force with L = 2/4/8 lanes
+//    per bot (batches that cannot fill the chip), and k_resident (simulations of <= 1024 bots: one
+//    workgroup per simulation, state in registers/LDS, many timesteps per launch).
+//  * k_force_stream is the one kernel that is NOT bit-identical: the opt-in streamlined arithmetic
+//    of force variant 3.
 #include <cstring>
 #include <string>
 #include <type_traits>
