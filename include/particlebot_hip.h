@@ -136,7 +136,8 @@ int pbSimCreate(pbSim **out, const SimParams *params, float wallHalf);
 void pbSimDestroy(pbSim *sim);
 
 /* A BATCH of nsims independent simulations (an ensemble: seeds, sweep points) stepped together by
- * the same kernel launches: params is an array of nsims blocks.  All members must share nCells,
+ * the same kernel launches: params is an array of nsims blocks (at most 2^28 bots in total).  All
+ * members must share nCells,
  * the grid, max_time, phase_update_interval, control and payload mode (nDead == -1 or not);
  * everything else (seed, light, obstacles, physics constants) may differ.  pbSimStep & co. advance
  * every member; the *Of functions address one member; pbSimCreate is the nsims == 1 case and the
@@ -209,8 +210,9 @@ int pbSimSetForceVariant(pbSim *sim, int variant);
 int pbSimSetLanesPerBot(pbSim *sim, int lanes);
 /* Resident form for simulations of at most 1024 bots: one workgroup per simulation keeps the state
  * in registers/LDS and runs every timestep up to the next re-sort, phase update or end of the
- * pbSimStep call in ONE launch.  0 = automatic (default: used when nbots <= 512, or <= 1024 in a
- * batch of at least 64), 1 = never, 2 = whenever the simulation fits.  Results do not depend on it. */
+ * pbSimStep call in ONE launch.  0 = automatic (default: a cost model fitted to MI355X measurements
+ * picks it for a lone simulation of ~100 bots and for ensembles of many small ones),
+ * 1 = never, 2 = whenever the simulation fits.  Results do not depend on it. */
 int pbSimSetResident(pbSim *sim, int mode);
 
 /* On-device check that the fast exact forms equal the compiler's IEEE sqrtf and division: every
