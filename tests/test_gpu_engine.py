@@ -438,3 +438,44 @@ def test_resident_is_automatic_for_small_simulations_only(pb, orc):
         _, gsim = make_pair(pb, orc, P)
         gsim.step(50)
         assert (gsim.stats()["resident_launches"] > 0) == expect, n
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_batch_in_the_throughput_form(pb, orc, variant):
+    """Ensemble members stepped by the one-bot-per-lane kernels (blockIdx.y = member), which large
+    batches use: forced here on 5 members of 1500 bots so that the oracle stays cheap.  Variant 2
+    (exact) must equal each member's oracle bit for bit; variant 3 (streamlined) must stay within
+    1e-5 relative of it over a 10-step window from the same exact state."""
+    members, osims, keep = [], [], []
+    for k in range(5):
+        P = orc.default_params(nCells=1500, nDead=0, seed=300 + k, light_x=-4.0 + k, light_y=0.5 * k,
+                               phase_std=0.0, max_time=1e9)
+        osims.append(orc.Sim(P))
+        sp, ka = simparams_from_orc(P)
+        members.append(sp)
+        keep.append(ka)
+    ens = pb.Ensemble(members, keepalive=keep)
+    ens.set_lanes_per_bot(1)
+    ens.set_resident(1)
+    ens.set_force_variant(2)
+    for k, osim in enumerate(osims):
+        ens.set_state_of(k, pos=osim.get("pos"), vel=osim.get("vel"), rad=osim.get("rad"), phase=osim.get("phase"),
+                         dead=osim.get("dead"))
+    for osim in osims:
+        osim.run(150)
+    assert ens.step(150) == 150
+    for k, osim in enumerate(osims):
+        st = ens.get_state_of(k)
+        for key in STATE_KEYS:
+            assert_bit_equal(st[key], osim.get(key), f"member {k}: {key}")
+    assert ens.stats()["fused_launches"] == 149
+    if variant == 3:
+        ens.set_force_variant(3)
+        for osim in osims:
+            osim.run(10)
+        assert ens.step(10) == 10
+        for k, osim in enumerate(osims):
+            p, ref = ens.get_state_of(k)["pos"].astype(np.float64), osim.get("pos").astype(np.float64)
+            dev = np.linalg.norm(p - ref, axis=1) / np.linalg.norm(ref, axis=1)
+            assert np.quantile(dev, 0.99) <= 1e-5 and (dev > 1e-5).sum() <= 8, (k, dev.max())
+            assert np.linalg.norm(p.mean(0) - ref.mean(0)) <= 1e-5 * np.linalg.norm(ref.mean(0))
