@@ -204,3 +204,38 @@ def test_grid_wrap_and_walls(pb, orc):
     st = gsim.get_state()
     dev = rel_dev(st["pos"], osim.get("pos"))
     assert np.quantile(dev, 0.99) <= RTOL and (dev > RTOL).sum() <= 8 and np.isfinite(st["pos"]).all(), dev.max()
+
+
+def test_contact_list_overflow(pb, orc):
+    """More contacts per bot than the lane's list in LDS holds (12): 60 bots piled into one cell.  The
+    overflowing contacts are evaluated in place; the result must still track the exact kernel."""
+    from helpers import jittered_blob
+    rng = np.random.default_rng(23)
+    n = 700
+    pos, vel, rad = jittered_blob(n, 0.17, rng, center=(5.0, 0.0))
+    pos[:60] = np.float32([5.0, 0.0]) + rng.uniform(-0.09, 0.09, (60, 2)).astype(np.float32)  # the pile
+    vel[:] = 0
+    P = orc.default_params(nCells=n, nDead=0, seed=9, phase_std=0.0, max_time=1e9, light_x=-3.0, light_y=0.0)
+    osim = orc.Sim(P, reset=False)
+    sp, keep = simparams_from_orc(P)
+    gsim = pb.Sim(sp, keepalive=keep)
+    zeros = np.zeros(n, np.float32)
+    for name, a in (("pos", pos), ("vel", vel), ("rad", rad), ("phase", zeros), ("dead", np.zeros(n, np.int32))):
+        osim.set(name, a)
+    gsim.set_state(pos=pos, vel=vel, rad=rad, phase=zeros, dead=np.zeros(n, np.int32))
+    gsim.set_lanes_per_bot(1)
+    gsim.set_resident(1)
+    gsim.set_force_variant(3)
+    # contacts per bot in the pile at the start (pairs closer than the sum of radii)
+    d = np.linalg.norm(pos[:60, None] - pos[None, :60], axis=-1) + np.eye(60) * 9
+    assert ((d < (rad[:60, None] + rad[None, :60])).sum(1) > 12).any()
+    osim.run(3)
+    assert gsim.step(3) == 3
+    st = gsim.get_state()
+    assert np.isfinite(st["pos"]).all() and np.isfinite(st["absForce_r"]).all()
+    dev = rel_dev(st["pos"], osim.get("pos"))
+    print(f"overflow: deviation median {np.median(dev):.2g} p99 {np.quantile(dev, 0.99):.2g} max {dev.max():.2g}")
+    assert np.quantile(dev, 0.95) <= RTOL
+    # repulsion sums agree too (they include the overflowed contacts)
+    fr_g, fr_o = st["absForce_r"][:60].astype(np.float64), osim.get("absForce_r")[:60].astype(np.float64)
+    assert np.median(np.abs(fr_g - fr_o) / np.maximum(fr_o, 1e-9)) <= 1e-4
