@@ -136,3 +136,34 @@ def test_zero_steps_and_repeated_calls(pb, orc):
         assert gsim.step(1) == 1
     osim.run(25)
     compare(osim, gsim, "25 single steps")
+
+
+def test_huge_arena_with_aliased_cells(pb, orc):
+    """Walls at +-2000 (the fast exact forms' limit is 2048) over the default 512^2 grid, whose span
+    is only 120 units: cells alias, so the stencil pairs bots that are thousands of units apart --
+    including pairs whose x or y coordinates differ by one ulp.  Bit for bit against the oracle."""
+    rng = np.random.default_rng(31)
+    n = 4000
+    pos = rng.uniform(-1990.0, 1990.0, (n, 2)).astype(np.float32)
+    # columns of bots sharing x (or differing by an ulp) at aliasing distance: 512 cells * 0.235
+    span = np.float32(512 * 0.235)
+    base = pos[:200].copy()
+    pos[200:400] = base + np.float32([1.0, 0.0]) * span * np.float32(3)
+    pos[400:600, 0] = np.nextafter(base[:, 0], np.float32(4000))
+    pos[400:600, 1] = base[:, 1] + span * np.float32(5)
+    pos = np.clip(pos, -1990, 1990).astype(np.float32)
+    vel = (rng.standard_normal((n, 2)) * 0.05).astype(np.float32)
+    rad = rng.uniform(0.0775, 0.1175, n).astype(np.float32)
+    P = orc.default_params(nCells=n, nDead=0, seed=5, phase_std=0.0, max_time=1e9, light_x=0.0, light_y=0.0,
+                           arena_half=2000.0, grid=512)
+    assert abs(P.cellSizeX - 0.235) < 0.01  # the default grid geometry, only the walls moved
+    for lanes in (1, 8):
+        osim, gsim = pair_with_state(pb, orc, P, pos, vel, rad, wall_half=2000.0)
+        gsim.set_lanes_per_bot(lanes)
+        gsim.set_resident(1)
+        step = 0
+        for k in (1, 4, 60):
+            osim.run(k - step, sort_interval=0.2)
+            gsim.step(k - step, sort_interval=0.2)
+            step = k
+            compare(osim, gsim, f"huge arena lanes={lanes} step {k}")
