@@ -121,8 +121,21 @@ def cpu_baseline(n_bots, pitch=LATTICE_PITCH, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or steps >= 5000:
             break
+    cores_used = orclib.lib().orc_num_threads()
+    # the same arena on ONE thread, for a per-core figure: a few steps are enough
+    orclib.lib().orc_set_num_threads(1)
+    t1 = time.perf_counter()
+    steps1 = 0
+    while True:
+        sim.run(1)
+        steps1 += 1
+        el1 = time.perf_counter() - t1
+        if el1 > min(3.0, budget_s / 4) or steps1 >= 200:
+            break
+    orclib.lib().orc_set_num_threads(cores_used)
     sim.close()
-    return {"value": n_bots * steps / el, "unit": "particle-steps/s", "cores": orclib.lib().orc_num_threads(),
+    return {"value": n_bots * steps / el, "unit": "particle-steps/s", "cores": cores_used,
+            "value_1_thread": n_bots * steps1 / el1,
             "kind": "port",
             "sample": f"{steps} steps of the same {n_bots}-bot arena after 1 warm-up step, OpenMP over bots "
                       f"({el:.1f} s); reported, not optimised"}
