@@ -90,27 +90,40 @@ __global__ __launch_bounds__(TILE) void k_state(const PbDevParams *__restrict__ 
   vel[s] = v;
 }
 
-// Ordered sum over the L lanes of a group: term e of the group is broadcast to all its lanes with
-// ds_swizzle in bit-mask mode (source lane = (lane & and_mask) | e, inside each 32-lane half; the
-// pattern must be an immediate, hence the compile-time recursion) and added, e = 0 .. L-1.
-template <int L, int E>
-struct GroupSum {
-  static __device__ __forceinline__ void add(const PbPairTerm &t, int flags, PbForce &F) {
-    constexpr int PAT = (E << 5) | (0x1F & ~(L - 1));
-    PbPairTerm u;
-    u.tx = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(t.tx), PAT));
-    u.ty = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(t.ty), PAT));
-    u.mag = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(t.mag), PAT));
-    const int fl = __builtin_amdgcn_ds_swizzle(flags, PAT);
-    u.contact = (fl & 2) != 0;
-    pbPairAdd((fl & 1) != 0, u, F);
-    GroupSum<L, E + 1>::add(t, flags, F);
-  }
-};
+// Ordered sum over the L lanes of a group, as a systolic chain: every lane holds the group's running
+// sums F (identical in all L lanes) and its own term t.  Step 1: a = F + t.  Steps 2..L: a = (a of the
+// lane to the left, a DPP row_shr:1 operand of the add itself) + t.  After L steps the group's LAST
+// lane holds ((F + t_0) + t_1) + ... + t_{L-1} -- the reference's order -- and broadcasts it back
+// (ds_swizzle).  Lanes further left hold partial chains that started in a neighbouring group; they
+// are never used.  A lane without a term (the bot's own slot, the tail of the list) adds +0, which
+// changes nothing (the sums are never -0).  4 quantities x (L adds + 1 broadcast) instructions per
+// trip; the former form (every lane fetching and adding all L terms itself) took ~12 L.
+__device__ __forceinline__ float pbShr1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+}
 template <int L>
-struct GroupSum<L, L> {
-  static __device__ __forceinline__ void add(const PbPairTerm &, int, PbForce &) {}
-};
+__device__ __forceinline__ float pbGroupLast(float v) {
+  // broadcast the value of the group's last lane to its L lanes (bit-mask mode, inside 32-lane halves)
+  constexpr int PAT = ((L - 1) << 5) | (0x1F & ~(L - 1));
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PAT));
+}
+template <int L>
+__device__ __forceinline__ void pbGroupSum(bool live, const PbPairTerm &t, PbForce &F) {
+  const float tx = live ? t.tx : 0.0f, ty = live ? t.ty : 0.0f;
+  const float ta = (live && !t.contact) ? t.mag : 0.0f, tr = (live && t.contact) ? t.mag : 0.0f;
+  float ax = F.fx + tx, ay = F.fy + ty, aa = F.fa + ta, ar = F.fr + tr;
+#pragma unroll
+  for (int e = 1; e < L; e++) {
+    ax = pbShr1(ax) + tx;
+    ay = pbShr1(ay) + ty;
+    aa = pbShr1(aa) + ta;
+    ar = pbShr1(ar) + tr;
+  }
+  F.fx = pbGroupLast<L>(ax);
+  F.fy = pbGroupLast<L>(ay);
+  F.fa = pbGroupLast<L>(aa);
+  F.fr = pbGroupLast<L>(ar);
+}
 
 // Flattened neighbour list of one bot (L > 1 form): plain scalars passed by value, so that they
 // stay in registers wherever the sweep is inlined (arrays or by-reference captures here ended up in
@@ -202,9 +215,8 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
       PbPairTerm t[1];
       pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
                            [&](int) { return velIn[j]; }, t);
-      const int flags = (live[0] ? 1 : 0) | (t[0].contact ? 2 : 0);
-      // every lane of the group adds the group's L terms in list order
-      GroupSum<L, 0>::add(t[0], flags, F);
+      // the group's L terms join the running sums in list order
+      pbGroupSum<L>(live[0], t[0], F);
     }
     return;
   }
@@ -1005,7 +1017,7 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
   // A per-step launch of a small or medium batch is bound by one wave's serial neighbour loop, not
   // by VALU throughput, so bots get L = 8 or 4 lanes each while the chip has lanes to spare
   // (measured on MI355X, one simulation on the bench lattice, us/step for L = 1/2/4/8:
-  //  10^4 bots 29/-/-/12, 6x10^4 31/25/21/24, 10^5 37/29/29/34, 2x10^5 39/45/48/58).
+  //  3x10^4 bots 25/18/13/12, 6x10^4 28/21/18.5/20, 10^5 32/26/25.7/29, 2x10^5 35/40/42/49).
   // Only the branch-free kernels have the multi-lane forms.
   int form = 0;
   if (kind != 0) {
@@ -1045,15 +1057,16 @@ bool residentWanted(const pbSim *S) {
   if (S->lanesPerBot != 0 && S->resident != 2) return false;  // an explicit per-step form was asked for
   if (S->resident == 2) return true;
   // automatic: cost model fitted to MI355X measurements (microseconds per timestep of the whole
-  // batch).  One CU per simulation costs ~6 + 0.033 n however many
-  // simulations there are (up to one per CU); a per-step launch costs a ~10 us dependent-latency
+  // batch).  One CU per simulation costs ~4 + 0.034 n however many
+  // simulations there are (up to one per CU); a per-step launch costs a ~7 us dependent-latency
   // floor plus a term in the TOTAL number of bots.  So the resident form wins for ensembles of
   // many small simulations and for single simulations of ~100 bots, and loses for a lone
   // simulation of a few hundred bots that per-step launches spread over many CUs.
   const double n = S->n, total = S->total;
-  const double residentUs = (6.0 + 0.033 * n) * (S->nsims > 256u ? S->nsims / 256.0 : 1.0);
-  const double perStepUs = total <= 49152.0 ? 10.5 + total / 3500.0
-                           : total <= 131072.0 ? 14.0 + total / 6500.0 : 22.0 + total / 5500.0;
+  const double residentUs =
+      ((S->nsims >= 64u ? 4.5 : 3.5) + 0.034 * n) * (S->nsims > 256u ? S->nsims / 256.0 : 1.0);
+  const double perStepUs = total <= 49152.0 ? 7.0 + total / 5500.0
+                           : total <= 131072.0 ? 9.0 + total / 6000.0 : 17.0 + total / 10300.0;
   return residentUs < perStepUs;
 }
 
