@@ -159,6 +159,15 @@ __device__ __forceinline__ uint32_t pbSegSlot(const PbSegList SL, uint32_t m, ui
   o = k >= SL.c9 ? SL.o9 : o;
   return k < m ? k + o : self;  // beyond the list: the bot's own slot, never accumulated
 }
+// the same when no row of the stencil wraps (segments 1, 3, 5, 7, 9 are empty): half the chain
+__device__ __forceinline__ uint32_t pbSegSlot5(const PbSegList SL, uint32_t m, uint32_t self, uint32_t k) {
+  uint32_t o = SL.o0;
+  o = k >= SL.c2 ? SL.o2 : o;
+  o = k >= SL.c4 ? SL.o4 : o;
+  o = k >= SL.c6 ? SL.o6 : o;
+  o = k >= SL.c8 ? SL.o8 : o;
+  return k < m ? k + o : self;
+}
 
 // Neighbour sweep of one bot: the 25-cell stencil as 5 grid rows x up to 2 slot ranges (x-wrap), in
 // the reference's order (impl.cuh:617-655).  prIn/velIn are indexed by (global slot - base): the
@@ -200,24 +209,32 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
       cum += hi - lo;
     }
     const uint32_t m = cum;
-    auto slotOf = [=](uint32_t k) __attribute__((always_inline)) { return pbSegSlot(SL, m, s, k); };
-    uint32_t jn = slotOf(sub);
-    float4 qn = prIn[jn];
-    for (uint32_t b0 = 0; b0 < m; b0 += L) {
-      const uint32_t j = jn;
-      const float4 q = qn;
-      jn = slotOf(b0 + L + sub);
-      qn = prIn[jn];
-      const bool live[1] = {j != s};
-      const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
-      const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
-      const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
-      PbPairTerm t[1];
-      pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
-                           [&](int) { return velIn[j]; }, t);
-      // the group's L terms join the running sums in list order
-      pbGroupSum<L>(live[0], t[0], F);
-    }
+    // wave-uniform: away from the x-wrap (nearly always) the position -> slot chain has 5 links, not 10
+    auto run = [&](auto wrapTag) __attribute__((always_inline)) {
+      constexpr bool WRAP = decltype(wrapTag)::value;
+      auto slotOf = [=](uint32_t k) __attribute__((always_inline)) {
+        return WRAP ? pbSegSlot(SL, m, s, k) : pbSegSlot5(SL, m, s, k);
+      };
+      uint32_t jn = slotOf(sub);
+      float4 qn = prIn[jn];
+      for (uint32_t b0 = 0; b0 < m; b0 += L) {
+        const uint32_t j = jn;
+        const float4 q = qn;
+        jn = slotOf(b0 + L + sub);
+        qn = prIn[jn];
+        const bool live[1] = {j != s};
+        const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
+        const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
+        const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
+        PbPairTerm t[1];
+        pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
+                             [&](int) { return velIn[j]; }, t);
+        // the group's L terms join the running sums in list order
+        pbGroupSum<L>(live[0], t[0], F);
+      }
+    };
+    if (__all(nseg == 1)) run(std::false_type{});
+    else run(std::true_type{});
     return;
   }
   if (FLAT && NB == 1) {
