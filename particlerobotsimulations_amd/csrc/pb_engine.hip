@@ -217,18 +217,20 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
       };
       uint32_t jn = slotOf(sub);
       float4 qn = prIn[jn];
+      float2 wn = velIn[jn];
       for (uint32_t b0 = 0; b0 < m; b0 += L) {
         const uint32_t j = jn;
         const float4 q = qn;
+        const float2 w = wn;
         jn = slotOf(b0 + L + sub);
         qn = prIn[jn];
+        wn = velIn[jn];
         const bool live[1] = {j != s};
         const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
         const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
         const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
         PbPairTerm t[1];
-        pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
-                             [&](int) { return velIn[j]; }, t);
+        pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K, [&](int) { return w; }, t);
         // the group's L terms join the running sums in list order
         pbGroupSum<L>(live[0], t[0], F);
       }
@@ -1074,15 +1076,15 @@ bool residentWanted(const pbSim *S) {
   if (S->lanesPerBot != 0 && S->resident != 2) return false;  // an explicit per-step form was asked for
   if (S->resident == 2) return true;
   // automatic: cost model fitted to MI355X measurements (microseconds per timestep of the whole
-  // batch).  One CU per simulation costs ~4 + 0.034 n however many
-  // simulations there are (up to one per CU); a per-step launch costs a ~7 us dependent-latency
+  // batch).  One CU per simulation costs ~3.5 + 0.031 n however many
+  // simulations there are (up to one per CU); a per-step launch costs a ~6 us dependent-latency
   // floor plus a term in the TOTAL number of bots.  So the resident form wins for ensembles of
-  // many small simulations and for single simulations of ~100 bots, and loses for a lone
-  // simulation of a few hundred bots that per-step launches spread over many CUs.
+  // many small simulations, and loses for a lone simulation that per-step launches spread over
+  // many CUs (at ~100 bots the two are equal).
   const double n = S->n, total = S->total;
   const double residentUs =
-      ((S->nsims >= 64u ? 4.5 : 3.5) + 0.034 * n) * (S->nsims > 256u ? S->nsims / 256.0 : 1.0);
-  const double perStepUs = total <= 49152.0 ? 7.0 + total / 5500.0
+      ((S->nsims >= 64u ? 4.0 : 3.0) + 0.031 * n) * (S->nsims > 256u ? S->nsims / 256.0 : 1.0);
+  const double perStepUs = total <= 49152.0 ? 6.0 + total / 5500.0
                            : total <= 131072.0 ? 9.0 + total / 6000.0 : 17.0 + total / 10300.0;
   return residentUs < perStepUs;
 }

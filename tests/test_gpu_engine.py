@@ -430,14 +430,22 @@ def test_resident_respects_max_time_and_call_boundaries(pb, orc):
     assert gsim.step(10) == 0
 
 
-def test_resident_is_automatic_for_small_simulations_only(pb, orc):
-    """The automatic choice follows the measured cost model: a lone ~100-bot simulation runs
-    resident, a lone larger one is spread over many CUs by per-step launches."""
-    for n, expect in ((100, True), (2000, False)):
-        P = orc.default_params(nCells=n, nDead=0, seed=4, phase_std=0.0, max_time=1e9)
-        _, gsim = make_pair(pb, orc, P)
-        gsim.step(50)
-        assert (gsim.stats()["resident_launches"] > 0) == expect, n
+def test_resident_is_automatic_for_small_ensembles_only(pb, orc):
+    """The automatic choice follows the measured cost model: an ensemble of many ~100-bot simulations
+    runs resident (one workgroup each); a lone larger simulation is spread over many CUs by
+    per-step launches."""
+    P = orc.default_params(nCells=2000, nDead=0, seed=4, phase_std=0.0, max_time=1e9)
+    _, gsim = make_pair(pb, orc, P)
+    gsim.step(50)
+    assert gsim.stats()["resident_launches"] == 0
+    members, keep = [], []
+    for k in range(128):
+        sp, ka = simparams_from_orc(orc.default_params(nCells=100, nDead=0, seed=10 + k, phase_std=0.0, max_time=1e9))
+        members.append(sp)
+        keep.append(ka)
+    ens = pb.Ensemble(members, keepalive=keep)
+    ens.step(50)
+    assert ens.stats()["resident_launches"] > 0
 
 
 @pytest.mark.parametrize("variant", [2, 3])
