@@ -169,6 +169,15 @@ __device__ __forceinline__ uint32_t pbSegSlot5(const PbSegList SL, uint32_t m, u
   return k < m ? k + o : self;
 }
 
+// A bot's flattened list only depends on the (stale) cell table and on the cell the bot is in; the
+// resident kernel keeps it across timesteps and rebuilds it (10 table reads) only in the steps in
+// which some bot of the wave has moved to another cell.
+struct PbSegCache {
+  PbSegList SL;
+  uint32_t m;
+  int gx, gy;
+};
+
 // Neighbour sweep of one bot: the 25-cell stencil as 5 grid rows x up to 2 slot ranges (x-wrap), in
 // the reference's order (impl.cuh:617-655).  prIn/velIn are indexed by (global slot - base): the
 // per-step kernel passes the HBM arrays and base 0, the resident kernel its LDS copy and the
@@ -178,10 +187,11 @@ __device__ __forceinline__ uint32_t pbSegSlot5(const PbSegList SL, uint32_t m, u
 // flattened neighbour list at a time, then every lane of the group adds the L terms in list order
 // (ds_swizzle broadcasts inside the group), so the sums -- and their order -- are those of L == 1.
 // The serial chain per bot shrinks ~L/2-fold at ~2x the total VALU work.
-template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, class PR, class VL>
-__device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
+template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, bool CACHED, class PR, class VL>
+__device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn,
                                         const uint32_t *__restrict__ cellS, uint32_t base, uint32_t s,
-                                        uint32_t sub, const float4 &me, const float2 &v, float att1, PbForce &F) {
+                                         uint32_t sub, const float4 &me, const float2 &v, float att1, PbForce &F,
+                                         PbSegCache &cache) {
   const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
   const float slope0 = pbBandSlope(P.attraction);
   const float attraction0 = P.attraction;
@@ -195,20 +205,33 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
     // 5 grid rows x up to 2 ranges (x-wrap) = 10 list segments; segment r covers list positions
     // [c[r], c[r+1]) and maps position k to slot k + o[r].
     PbSegList SL;
-    uint32_t cum = 0;
+    uint32_t m;
+    // (wave-uniform) rebuild unless every lane's cached list is still for the cell it is in
+    if (!CACHED || __any(cache.gx != gx || cache.gy != gy)) {
+      uint32_t cum = 0;
 #pragma unroll
-    for (int si = 0; si < 10; si++) {
-      const int sg = si & 1;
-      const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
-      uint32_t lo = 0, hi = 0;
-      if (sg < nseg) {
-        lo = cellS[row + (sg == 0 ? mx0 : 0u)] - base;
-        hi = cellS[row + (sg == 0 ? mx0 + first : 5u - first)] - base;
+      for (int si = 0; si < 10; si++) {
+        const int sg = si & 1;
+        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+        uint32_t lo = 0, hi = 0;
+        if (sg < nseg) {
+          lo = cellS[row + (sg == 0 ? mx0 : 0u)] - base;
+          hi = cellS[row + (sg == 0 ? mx0 + first : 5u - first)] - base;
+        }
+        SL.set(si, lo - cum, cum);
+        cum += hi - lo;
       }
-      SL.set(si, lo - cum, cum);
-      cum += hi - lo;
+      m = cum;
+      if (CACHED) {
+        cache.SL = SL;
+        cache.m = m;
+        cache.gx = gx;
+        cache.gy = gy;
+      }
+    } else {
+      SL = cache.SL;
+      m = cache.m;
     }
-    const uint32_t m = cum;
     // wave-uniform: away from the x-wrap (nearly always) the position -> slot chain has 5 links, not 10
     auto run = [&](auto wrapTag) __attribute__((always_inline)) {
       constexpr bool WRAP = decltype(wrapTag)::value;
@@ -370,6 +393,14 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
       }
     }
   }
+}
+
+template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, class PR, class VL>
+__device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn, const uint32_t *__restrict__ cellS,
+                                        uint32_t base, uint32_t s, uint32_t sub, const float4 &me, const float2 &v,
+                                        float att1, PbForce &F) {
+  PbSegCache none;
+  pbSweepC<PAYLOAD, FLAT, FAST, L, NB, false>(P, prIn, velIn, cellS, base, s, sub, me, v, att1, F, none);
 }
 
 // Forces + kick of step n (impl.cuh:657-831); with FUSE also radius + integration of step n+1.
@@ -612,6 +643,9 @@ __global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict
   if (PAYLOAD) selfPayload = (orig[s] == P.nCells - 1u);
   const float att1 = selfPayload ? P.attractionFactor : 1.0f;
 
+  PbSegCache segCache;
+  segCache.gx = segCache.gy = (int)0x80000000;  // no cell yet
+  segCache.m = 0;
   float t = time0;
   // radius actuation + integration of the first step (k_state)
   if (lightWave && t >= 0) me.z = pbActuate(P, me.z, ph, dd, fa, fr, t, dt);
@@ -633,9 +667,9 @@ __global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict
       const float4 *prIn = sPr[cur];
       const float2 *velIn = sVel[cur];
       if (FASTOK && __all(pbLaneFastMathOk(me.x, me.y)))
-        pbSweep<PAYLOAD, true, true, L, 1>(P, prIn, velIn, cellS, base, l, sub, me, v, att1, F);
+        pbSweepC<PAYLOAD, true, true, L, 1, (L > 1)>(P, prIn, velIn, cellS, base, l, sub, me, v, att1, F, segCache);
       else
-        pbSweep<PAYLOAD, true, false, L, 1>(P, prIn, velIn, cellS, base, l, sub, me, v, att1, F);
+        pbSweepC<PAYLOAD, true, false, L, 1, (L > 1)>(P, prIn, velIn, cellS, base, l, sub, me, v, att1, F, segCache);
       pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
       pbFrictionAndKick(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
       fa = F.fa;
