@@ -61,3 +61,35 @@ def test_engine_rejects_bad_arguments_without_a_gpu(capi):
     p, keep = capi.make_params({"gridSize": (500, 512), "numCells": 500 * 512, "nCells": 10})
     assert L.pbSimCreate(C.byref(h), C.byref(p), 0.0) == 2
     assert b"power of two" in L.pbGetLastErrorString()
+
+
+def test_engine_error_paths_without_a_gpu(capi):
+    """Every argument check of pbSimCreate[Batch] runs before the device is touched, and a valid
+    request on a machine without a GPU fails with PB_ERR_NO_DEVICE and a message (never a crash,
+    never a CPU fallback).  Setters and getters reject a null handle."""
+    import ctypes as C
+    L = capi.lib()
+    h = C.c_void_p()
+    ok, keep = capi.make_params({"gridSize": (512, 512), "numCells": 512 * 512, "nCells": 10})
+    assert L.pbSimCreate(None, C.byref(ok), 0.0) == 2
+    zero, k0 = capi.make_params({"gridSize": (512, 512), "numCells": 512 * 512, "nCells": 0})
+    assert L.pbSimCreate(C.byref(h), C.byref(zero), 0.0) == 2 and b"nCells" in L.pbGetLastErrorString()
+    tiny, k1 = capi.make_params({"gridSize": (4, 4), "numCells": 16, "nCells": 10})
+    assert L.pbSimCreate(C.byref(h), C.byref(tiny), 0.0) == 2
+    # batch: nsims < 1, mismatched members, too many bots for 32-bit byte offsets
+    assert L.pbSimCreateBatch(C.byref(h), C.byref(ok), 0, 0.0) == 2
+    other, k2 = capi.make_params({"gridSize": (512, 512), "numCells": 512 * 512, "nCells": 11})
+    arr = (capi.SimParams * 2)(ok, other)
+    assert L.pbSimCreateBatch(C.byref(h), arr, 2, 0.0) == 2 and b"must share" in L.pbGetLastErrorString()
+    big, k3 = capi.make_params({"gridSize": (512, 512), "numCells": 512 * 512, "nCells": 200_000_000})
+    arr2 = (capi.SimParams * 2)(big, big)
+    assert L.pbSimCreateBatch(C.byref(h), arr2, 2, 0.0) == 2 and b"2^28" in L.pbGetLastErrorString()
+    # a valid request: no device here
+    import torch
+    if not torch.cuda.is_available():
+        rc = L.pbSimCreate(C.byref(h), C.byref(ok), 0.0)
+        assert rc == 3 and b"no HIP device" in L.pbGetLastErrorString() and not h.value
+    # null handles
+    assert L.pbSimStep(None, C.c_float(0.01), C.c_float(180.0), 1, None) == 2
+    assert L.pbSimSetForceVariant(None, 2) == 2 and L.pbSimSetLanesPerBot(None, 8) == 2
+    assert L.pbSimSetResident(None, 0) == 2 and L.pbSimGetTime(None, None) == 2
