@@ -167,3 +167,45 @@ def test_huge_arena_with_aliased_cells(pb, orc):
             gsim.step(k - step, sort_interval=0.2)
             step = k
             compare(osim, gsim, f"huge arena lanes={lanes} step {k}")
+
+
+@pytest.mark.parametrize("trial", range(14))
+def test_random_parameter_sets(pb, orc, trial):
+    """Deterministic 'fuzz' over the parameter space the examples never visit: spring, dashpot, shear,
+    friction, gravity, attraction, radii, actuation period, constraint, constrained contraction on and
+    off, all three light_shadow modes behind obstacles, phase noise, payload factors, wall damping --
+    every draw stepped through a phase update with frequent re-sorts and compared bit for bit."""
+    rng = np.random.default_rng(9000 + trial)
+    n = int(rng.choice([60, 130, 300, 700, 1500]))
+    payload = trial % 4 == 3
+    rmin = float(rng.uniform(0.05, 0.09))
+    kw = dict(
+        nCells=n, nDead=-1 if payload else 0, seed=int(rng.integers(1, 10**6)), max_time=1e9,
+        light_x=float(rng.uniform(-8, 8)), light_y=float(rng.uniform(-8, 8)),
+        spring=float(rng.uniform(200, 3000)), damping=float(rng.uniform(0, 30)), shear=float(rng.uniform(0, 60)),
+        friction=float(rng.uniform(0.05, 0.9)), gravity=float(rng.uniform(1, 9.81)),
+        attraction=float(rng.choice([0.0, 1e-6, 4.8e-5, 1e-3])), boundaryDamping=float(rng.choice([-1.0, -0.5])),
+        min_radius=rmin, max_radius=rmin * float(rng.uniform(1.2, 1.8)), rise_period=float(rng.choice([1.0, 2.0, 3.0])),
+        Nx=int(rng.integers(2, 8)), constraint=float(rng.uniform(0.1, 2.0)),
+        constrained_contraction=int(trial % 2), constraint_contraction=float(rng.uniform(1, 20)),
+        phase_std=float(rng.choice([0.0, 0.3, 1.0])), phase_update_interval=12.0,
+        light_shadow=int(trial % 3), massFactor=float(rng.uniform(1, 3)), frictionFactor=float(rng.uniform(0.5, 2)),
+        attractionFactor=float(rng.uniform(0.1, 1.0)), radFactor=float(rng.uniform(1.0, 2.5)))
+    if trial % 3:
+        kw.update(n_cir_obstacles=2, x_cir_obs=[2.0, 6.5], y_cir_obs=[0.5, -1.0], r_cir_obs=[0.4, 0.3],
+                  nobstacles=1, x1obs=[3.0], x2obs=[3.2], y1obs=[-2.0], y2obs=[-0.6])
+    P = orc.default_params(**kw)
+    osim = orc.Sim(P, reset=True)
+    sp, keep = simparams_from_orc(P)
+    gsim = pb.Sim(sp, keepalive=keep)
+    gsim.set_state(pos=osim.get("pos"), vel=osim.get("vel"), rad=osim.get("rad"), phase=osim.get("phase"),
+                   dead=osim.get("dead"))
+    if trial % 5 == 4:
+        gsim.set_lanes_per_bot(1)
+    si = float(rng.choice([0.23, 1.7, 180.0]))
+    step = 0
+    for k in (1, 7, 400, 1210):
+        osim.run(k - step, sort_interval=si)
+        assert gsim.step(k - step, sort_interval=si) == k - step
+        step = k
+        compare(osim, gsim, f"trial {trial} n={n} step {k}")
