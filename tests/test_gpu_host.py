@@ -224,3 +224,39 @@ def test_million_bot_cfg_runs_headless(tmp_path):
     assert len(rows) >= 3
     last = [float(x) for x in rows[-1].strip(",").split(",")]
     assert abs(last[1]) < 1e-3 and abs(last[2]) < 1e-3 and 229.9 < last[3] < 230.1
+
+
+@pytest.mark.parametrize("trial", range(6))
+def test_random_cfg_files_end_to_end(host, orc, tmp_path, trial):
+    """Loader + class (placement, dead-bot draw, dump schedule) + fused engine on randomly written
+    .cfg files, against the oracle's loader + whole-simulation object: the CSV is byte-identical and
+    so is every state array at the end."""
+    rng = np.random.default_rng(700 + trial)
+    n = int(rng.integers(40, 400))
+    lines = ["# random configuration %d" % trial,
+             "nCells", str(n),
+             "nDead", str(int(rng.integers(0, n // 3)) if trial % 3 else (-1 if trial == 3 else 0)),
+             "seed", str(int(rng.integers(1, 99999))),
+             "light_x", f"{rng.uniform(-6, 6):.3f}", "light_y", f"{rng.uniform(-6, 6):.3f}",
+             "time_to_dead", f"{rng.uniform(0.02, 0.5):.3f}",
+             "spring", f"{rng.uniform(300, 2000):.1f}", "damping", f"{rng.uniform(1, 20):.2f}",
+             "shear", f"{rng.uniform(5, 50):.2f}", "friction", f"{rng.uniform(0.1, 0.8):.3f}",
+             "phase_std", f"{rng.choice([0.0, 0.4, 0.9])}", "rise_period", f"{rng.choice([1, 2, 3])}",
+             "dump_interval", f"{rng.choice([0.25, 0.5])}", "testing", str(trial % 2),
+             "max_time", f"{rng.uniform(1.0, 1.6):.2f}",
+             "csv_filename", "unused.csv"]
+    if trial % 2:
+        lines += ["n_cir_obstacles", "2", "x_cir_obs", "2.5 6.0", "y_cir_obs", "0.4 -0.8", "r_cir_obs", "0.35 0.3",
+                  "light_shadow", str(1 + trial % 2)]
+    if trial == 3:
+        lines += ["massFactor", "2.0", "attractionFactor", "0.4", "radFactor", "1.5", "frictionFactor", "1.3"]
+    cfg = tmp_path / f"random{trial}.cfg"
+    cfg.write_text("\n".join(lines) + "\n")
+    a, b = str(tmp_path / "oracle.csv"), str(tmp_path / "product.csv")
+    gsim = product_csv(host, str(cfg), b, "fused")          # product first (it calls srand())
+    osim = oracle_csv(orc, str(cfg), a)
+    da, db = open(a, "rb").read(), open(b, "rb").read()
+    assert da.count(b"\n") >= 3 and da == db
+    for k in ("pos", "vel", "rad", "phase"):
+        assert_bit_equal(gsim.get(k), osim.get(k), k)
+    assert_bit_equal(gsim.get("dead"), osim.get("dead"), "dead")
