@@ -203,10 +203,11 @@ int pbSimSetResortEveryStep(pbSim *sim, int on);
  * replaces the throughput form (batches above 131072 bots, or lanes-per-bot forced to 1); smaller
  * batches keep running the exact kernels. */
 int pbSimSetForceVariant(pbSim *sim, int variant);
-/* Lanes per bot in the per-step force kernel: 1 = throughput form (one bot per lane); 2, 4, 8 =
+/* Lanes per bot in the per-step force kernel: 1 = throughput form (one bot per lane); 2, 4, 8, 16 =
  * that many adjacent lanes share a bot's neighbour list and add the terms in list order (batches
  * too small to fill the chip: the serial neighbour loop is the limit); 0 = automatic (default:
- * 8 up to 49152 bots in the batch, 4 up to 131072, else 1).  Results do not depend on it. */
+ * 16 up to 8192 bots in the batch, 8 up to 49152, 4 up to 131072, else 1).  Results do not depend
+ * on it. */
 int pbSimSetLanesPerBot(pbSim *sim, int lanes);
 /* Resident form for simulations of at most 1024 bots: one workgroup per simulation keeps the state
  * in registers/LDS and runs every timestep up to the next re-sort, phase update or end of the

@@ -1070,17 +1070,20 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
   // A per-step launch of a small or medium batch is bound by one wave's serial neighbour loop, not
   // by VALU throughput, so bots get L = 8 or 4 lanes each while the chip has lanes to spare
   // (measured on MI355X, one simulation on the bench lattice, us/step for L = 1/2/4/8:
-  //  3x10^4 bots 25/18/13/12, 6x10^4 28/21/18.5/20, 10^5 32/26/25.7/29, 2x10^5 35/40/42/49).
+  //  3x10^4 bots 25/18/13/12, 6x10^4 28/21/18.5/20, 10^5 32/26/25.7/29, 2x10^5 35/40/42/49;
+  //  L = 8 vs 16: 300 bots 6.4/5.7, 4000 bots 7.0/6.0, 10^4 bots 7.8/8.0).
   // Only the branch-free kernels have the multi-lane forms.
   int form = 0;
   if (kind != 0) {
     const int want = S->lanesPerBot;
-    if (want == 8 || (want == 0 && S->total <= 49152u)) form = 8;
+    if (want == 16 || (want == 0 && S->total <= 8192u)) form = 16;
+    else if (want == 8 || (want == 0 && S->total <= 49152u)) form = 8;
     else if (want == 4 || (want == 0 && S->total <= 131072u)) form = 4;
     else if (want == 2) form = 2;
   }
 #define PB_CASE(F, PL, K, FL, FA)                                                                        \
   if (fuse == F && payload == PL && kind == K) {                                                         \
+    if (FL && form == 16) return launchForceT<F, PL, FL, FA, (FL ? 16 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 8) return launchForceT<F, PL, FL, FA, (FL ? 8 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 4) return launchForceT<F, PL, FL, FA, (FL ? 4 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 2) return launchForceT<F, PL, FL, FA, (FL ? 2 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
@@ -1111,14 +1114,14 @@ bool residentWanted(const pbSim *S) {
   if (S->resident == 2) return true;
   // automatic: cost model fitted to MI355X measurements (microseconds per timestep of the whole
   // batch).  One CU per simulation costs ~3.5 + 0.031 n however many
-  // simulations there are (up to one per CU); a per-step launch costs a ~6 us dependent-latency
+  // simulations there are (up to one per CU); a per-step launch costs a ~5.5 us dependent-latency
   // floor plus a term in the TOTAL number of bots.  So the resident form wins for ensembles of
   // many small simulations, and loses for a lone simulation that per-step launches spread over
   // many CUs (at ~100 bots the two are equal).
   const double n = S->n, total = S->total;
   const double residentUs =
       ((S->nsims >= 64u ? 4.0 : 3.0) + 0.031 * n) * (S->nsims > 256u ? S->nsims / 256.0 : 1.0);
-  const double perStepUs = total <= 49152.0 ? 6.0 + total / 5500.0
+  const double perStepUs = total <= 49152.0 ? 5.3 + total / 5500.0
                            : total <= 131072.0 ? 9.0 + total / 6000.0 : 17.0 + total / 10300.0;
   return residentUs < perStepUs;
 }
@@ -1659,7 +1662,7 @@ int pbSimSetForceVariant(pbSim *S, int variant) {
 }
 
 int pbSimSetLanesPerBot(pbSim *S, int lanes) {
-  if (!S || !(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8)) return PB_ERR_ARG;
+  if (!S || !(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16)) return PB_ERR_ARG;
   S->lanesPerBot = lanes;
   return PB_OK;
 }
