@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- particle-steps/s of the particle-robot update loop on MI355X.
 
-Workload (BASELINE.json configs[2]): 10^6 oscillating bots on a hexagonal
-lattice (spacing 2*min_radius) in the generalised arena (2048^2 grid, walls +-240), one light at
+Workload (BASELINE.json configs[2]): 10^6 oscillating bots on a square
+lattice (pitch 2*min_radius; see LATTICE_PITCH below) in the generalised arena (2048^2 grid, walls +-240), one light at
 (-230, 0), phase_std 0, dt 0.01, sort_interval 180.  A "step" is one timestep of the whole arena:
 radius actuation + integration + neighbour forces + friction for every bot (one fused kernel).
 State is resident in HBM before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--bots B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--bots B] [--workload arena|ensemble4|ensemble5]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path does not shard a single
-arena (neighbour forces couple every cell each step), so every rank runs its own independent arena
--- an ensemble member with its own seed offset -- with no collective in the
-timed region; rank 0 gathers the per-arena centroid summaries over RCCL afterwards.
+N > 1 (launched by torch.distributed.run, one rank per GPU; a bare `python bench.py --gpus N` starts
+the N ranks itself as a child process): the path does not shard a single arena (neighbour forces
+couple every cell each step), so with --workload arena every rank runs its own independent arena --
+an ensemble member with its own seed offset -- with no collective in the timed
+region; rank 0 gathers the per-arena centroid summaries over RCCL afterwards.  --workload ensemble4 /
+ensemble5 run BASELINE configs[3] / configs[4]: batched ensembles of the reference's example
+configurations, member k on rank k mod N, the summary rows gathered over RCCL at the end.
 """
 import argparse
 import json
@@ -145,6 +148,9 @@ def make_sim(pb, n, pitch, seed, lattice="square"):
     import numpy as np
     sp, keep = workload_params(n, seed=seed)
     sim = pb.Sim(sp, wall_half=240.0, keepalive=keep)
+    sim.set_force_variant(2)   # the exact kernel, whatever the environment says (legs that want 3 set it)
+    sim.set_lanes_per_bot(0)
+    sim.set_resident(0)
     pos = square_lattice(n, pitch) if lattice == "square" else hex_lattice(n, np.float32(pitch))
     sim.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
                   phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
@@ -205,13 +211,262 @@ def streamlined_leg(pb, n, pitch, steps, warmup):
 
 
 def profiled_traffic():
-    """HBM bytes per k_force launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/latest_traffic.json, written by tools/profile.sh); None if absent."""
+    """HBM bytes per k_force launch and its VALU instruction counts from the committed rocprofv3 PMC
+    passes of this same command (profiles/latest_traffic.json, written by tools/profile.sh); None if
+    absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as fh:
             return json.load(fh)
     except Exception:
         return None
+
+
+SIMDS = 1024                 # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md)
+DATASHEET_CYC_SIMPLE = 2.0   # cycles per wave64 VALU instruction per SIMD ("v_fma_f32 (wave64) 2 cyc")
+DATASHEET_CYC_TRANS = 4.0    # v_rcp/v_sqrt/v_rsq: twice a simple one (the guide's single-wave issue costs 8 : 4)
+NOMINAL_MHZ = 2400.0
+
+
+def valu_roofline(tr, n, avg_launch_us, clock_mhz):
+    """The force kernel's VALU instruction stream (PMC counts per wave from the committed profile)
+    priced two ways against this run's launch time: (a) at the datasheet issue rate -- 2 cycles per
+    wave64 instruction per SIMD-32, 4 for a transcendental -- at the shader clock MEASURED under this
+    load (and, for reference, at the 2.4 GHz nominal clock); (b) at the rates tools/valu_rate measured
+    on the profiled box at 8 waves per SIMD."""
+    if not tr or "valu_insts_per_wave" not in tr or "trans_per_wave" not in tr:
+        return None
+    per_wave, trans = tr["valu_insts_per_wave"], tr["trans_per_wave"]
+    waves_per_simd = (n / 64.0) / SIMDS
+    cycles = ((per_wave - trans) * DATASHEET_CYC_SIMPLE + trans * DATASHEET_CYC_TRANS) * waves_per_simd
+    out = {"valu_insts_per_wave": per_wave, "trans_per_wave": trans, "waves_per_simd": waves_per_simd,
+           "datasheet_cycles_per_simd": cycles,
+           "datasheet_rate": {"cycles_per_simple": DATASHEET_CYC_SIMPLE, "cycles_per_trans": DATASHEET_CYC_TRANS},
+           "shader_clock_mhz_measured": clock_mhz,
+           "frac_datasheet_at_nominal_clock": cycles / NOMINAL_MHZ / avg_launch_us,
+           "frac_datasheet_at_measured_clock": (cycles / clock_mhz / avg_launch_us) if clock_mhz else None,
+           "source": "profiles/latest_traffic.json (SQ_INSTS_VALU, SQ_INSTS_VALU_TRANS_F32, SQ_WAVES)"}
+    if "ns_simple" in tr and "ns_trans" in tr:
+        us = ((per_wave - trans) * tr["ns_simple"] + trans * tr["ns_trans"]) * waves_per_simd * 1e-3
+        out["frac_microbenchmark_rate"] = us / avg_launch_us
+        out["microbenchmark_rate"] = {"ns_simple": tr["ns_simple"], "ns_trans": tr["ns_trans"],
+                                      "in_kernel_mhz": tr.get("valu_rate_mhz"),
+                                      "source": "tools/valu_rate at 8 waves/SIMD on the profiled box"}
+    for k in ("wave_cycle_split", "valu_lane_utilisation"):
+        if k in tr:
+            out[k] = tr[k]
+    return out
+
+
+def measure_clock(pb, sim, steps, ms_per_step):
+    """Shader clock held while the force kernel runs: a sleeping sampler wave on its own stream spans
+    ~80 % of `steps` more steps of the same simulation (NOT part of `value`'s timed region)."""
+    try:
+        span = max(0.02, min(5.0, 0.8 * steps * ms_per_step * 1e-3))
+        smp = pb.ClockSample(span)
+        sim.step(steps)
+        sim.synchronize()
+        return smp.end(), span
+    except Exception as e:  # diagnostic only
+        return None, str(e)
+
+
+def large_arena_leg(pb, pitch, warmup, steps, n=8_000_000):
+    """SURVEY 8(d) caveat 2: the same lattice at 8 x 10^6 bots (544 MB of state, beyond the 256 MiB
+    Infinity Cache) to show the kernel's sensitivity to true HBM traffic."""
+    sim = make_sim(pb, n, pitch, seed=1)
+    sim.step(warmup)
+    s0 = sim.stats()
+    done, ms = sim.step_timed(steps)
+    s1 = sim.stats()
+    cx, cy = sim.centroid()
+    cfg = sim.config()
+    sim.close()
+    launches = (s1["fused_launches"] - s0["fused_launches"]) + (s1["plain_launches"] - s0["plain_launches"])
+    us = ms * 1e3 / max(launches, 1)
+    achieved = ALG_BYTES_PER_PARTICLE_STEP * n / (us * 1e-6) / 1e9
+    return {"bots": n, "steps": done, "warmup": warmup, "us_per_step": us, "us_per_step_per_1e6_bots": us / (n / 1e6),
+            "value": n * done / (ms * 1e-3), "unit": "particle-steps/s (device time)",
+            "state_bytes": 68 * n, "finite_at_end": bool(cx == cx and cy == cy),
+            "force_variant": cfg["force_variant"], "lanes_per_bot": cfg["lanes_per_bot"],
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS},
+            "note": "working set beyond the Infinity Cache: if HBM bound the step would cost > 8x the 10^6-bot one"}
+
+
+# ---- ensemble workloads (BASELINE configs[3] and configs[4]) -------------------------------------
+ENSEMBLE_WORKLOADS = {
+    # name -> list of batches: (cfg, common overrides, per-member override maker)
+    "ensemble4": "examples/example_obstacle.cfg + examples/example_object_transport.cfg, Monte-Carlo seeds "
+                 "1000+k (BASELINE configs[3]); per GPU one batched pbSim per .cfg, both driven concurrently",
+    "ensemble5": "examples/example_dead_cells.cfg at nCells 100000, light (-40,0), dead fraction swept 0..0.40 "
+                 "over the members (BASELINE configs[4]); per GPU one batched pbSim",
+}
+
+
+def ensemble_batches(workload, rank, world, members_per_gpu):
+    """[(cfg_path, common, [override text per local member], [global member ids])] for this rank.
+    Global member k -> rank k mod world (ensemble.shard), so N GPUs run N x members_per_gpu members."""
+    from particlerobotsimulations_amd import ensemble
+    total = members_per_gpu * world
+    ids = ensemble.shard(total, rank, world)
+    ex = lambda name: os.path.join(ROOT, "examples", name)
+    big = {"max_time": "1e9", "dump_interval": "6"}
+    if workload == "ensemble4":
+        return [(ex("example_obstacle.cfg"), big, [f"seed\n{1000 + k}" for k in ids], ids),
+                (ex("example_object_transport.cfg"), big, [f"seed\n{1000 + k}" for k in ids], ids)]
+    common = dict(big, nCells="100000", light_x="-40", light_y="0")
+    over = []
+    for k in ids:
+        f = 0.40 * (k % 64) / 63.0
+        over.append(f"seed\n{1000 + k // 64}\nnDead\n{int(round(f * 100000))}")
+    return [(ex("example_dead_cells.cfg"), common, over, ids)]
+
+
+def run_ensemble_workload(args, rank, world, dist, torch):
+    import threading
+
+    import numpy as np
+    from particlerobotsimulations_amd import ensemble, host
+    batches = ensemble_batches(args.workload, rank, world, args.members_per_gpu)
+    t_place = time.perf_counter()
+    ens = [ensemble.LocalEnsemble(cfg, over, common) for cfg, common, over, _ in batches]
+    t_place = time.perf_counter() - t_place
+
+    def drive(nsteps):
+        """nsteps timesteps of every member; the batches of this rank run concurrently (one host
+        thread per batch: each pbSim has its own HIP stream, ctypes releases the GIL)."""
+        done = [0] * len(ens)
+
+        def one(i):
+            done[i] = ens[i].run_steps(nsteps)
+        th = [threading.Thread(target=one, args=(i,)) for i in range(1, len(ens))]
+        for t in th:
+            t.start()
+        one(0)
+        for t in th:
+            t.join()
+        return done
+
+    def barrier():
+        for e in ens:
+            e.synchronize()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    drive(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    done = drive(args.steps)
+    barrier()
+    wall = time.perf_counter() - t0
+    assert all(d == args.steps for d in done), (done, args.steps)
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    # the path's only exchange: every member's summary rows, gathered once over RCCL
+    total_members = args.members_per_gpu * world
+    gathered = [ensemble.gather_summaries(e.rows, total_members, rank, world, dist,
+                                          "cuda" if dist is not None else "cpu") for e in ens]
+    bots = [e.n for e in ens]
+    if rank == 0:
+        per_gpu_bots = sum(b * args.members_per_gpu for b in bots)
+        value = world * per_gpu_bots * args.steps / wall
+        achieved = ALG_BYTES_PER_PARTICLE_STEP * per_gpu_bots * args.steps / wall / 1e9
+        last = [g[:, -1] for g in gathered]
+        assert all(np.isfinite(l).all() for l in last), "an ensemble member went NaN"
+        out = {
+            "metric": "particle-steps/sec at 10^6 bots; achieved HBM GB/s vs peak; 1/2/4/8-GPU ensemble",
+            "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {ENSEMBLE_WORKLOADS[args.workload]}",
+                       "members_per_gpu": args.members_per_gpu * len(ens), "members_total": total_members * len(ens),
+                       "bots_per_member": bots, "dt": 0.01,
+                       "parallelism": f"member k -> rank k mod {world}; one batched pbSim per .cfg per GPU; "
+                                      f"RCCL world size {dist.get_world_size() if dist is not None else 1}"
+                                      if dist is not None else "one GPU, no process group",
+                       "members_per_rank": [len(ensemble.shard(total_members, r, world)) * len(ens)
+                                            for r in range(world)]},
+            "sims_per_s": world * args.members_per_gpu * len(ens) / wall,
+            "placement_s": t_place,
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_resident (<= 1024-bot members) / k_force (larger members)",
+                         "note": "64 algorithmic bytes per particle-step over WALL time of the timed region "
+                                 "(host-driven schedule included); small members are latency-bound (DESIGN.md 6b)"},
+            "summaries_last_row_time_comx_comy_dist": [[[float(x) for x in r] for r in l[:4]] for l in last],
+            "summary_rows_gathered": [list(g.shape) for g in gathered],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_ensemble(batches, min(args.cpu_seconds, 10.0))
+        emit(out)
+    for e in ens:
+        e.close()
+
+
+def cpu_baseline_ensemble(batches, budget_s):
+    """The oracle (CPU port; the reference has no CPU path) on ONE member of each batch for a bounded
+    time: placement excluded, timesteps only."""
+    from oracle import orclib
+    cores = orclib.usable_cpus()
+    orclib.lib().orc_set_num_threads(cores)
+    work, el = 0.0, 0.0
+    parts = []
+    for cfg, common, over, _ in batches:
+        kv = dict(common)
+        lines = over[0].split("\n")
+        kv.update({lines[i]: lines[i + 1] for i in range(0, len(lines), 2)})
+        P = orclib.OrcParams()
+        L = orclib.lib()
+        import ctypes as C
+        L.orc_params_defaults(C.byref(P))
+        L.orc_load_cfg(C.byref(P), os.fsencode(cfg))
+        for k, v in kv.items():
+            L.orc_set_param(C.byref(P), k.encode(), str(v).encode())
+        L.orc_params_derive(C.byref(P), 0, 0.0)
+        sim = orclib.Sim(P)
+        sim.run(1)
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < budget_s / len(batches) and steps < 100000:
+            sim.run(10)
+            steps += 10
+        dt = time.perf_counter() - t0
+        work += float(P.nCells) * steps
+        el += dt
+        parts.append(f"{steps} steps of one {P.nCells}-bot member of {os.path.basename(cfg)}")
+        sim.close()
+    return {"value": work / el, "unit": "particle-steps/s", "cores": orclib.lib().orc_num_threads(), "kind": "port",
+            "sample": "; ".join(parts) + " (OpenMP over bots; reported, not optimised)"}
+
+
+def emit(out):
+    # the ONE JSON line goes last: push out whatever C libraries (RCCL's version banner) still hold
+    # in stdio buffers first
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- as a CHILD process,
+    before this one has made any HIP or torch.cuda call -- and pass its exit code on."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()  # (does not initialise the GPU)
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible\n")
+        return 2
+    port = str(29500 + (os.getpid() % 400))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -221,17 +476,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--bots", type=int, default=1_000_000)
     ap.add_argument("--pitch", type=float, default=LATTICE_PITCH)
+    ap.add_argument("--workload", choices=["arena", "ensemble4", "ensemble5"], default="arena",
+                    help="arena: the 10^6-bot headline (BASELINE configs[2]); ensemble4 / ensemble5: BASELINE "
+                         "configs[3] / configs[4] as batched ensembles sharded member k -> rank k mod N")
+    ap.add_argument("--members-per-gpu", type=int, default=None,
+                    help="ensemble workloads: members per GPU and per .cfg (default 32 for ensemble4, 8 for ensemble5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-survey-literal", action="store_true")
     ap.add_argument("--no-streamlined", action="store_true")
+    ap.add_argument("--no-large-arena", action="store_true")
+    ap.add_argument("--no-clock", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the cpu_baseline sample")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path")
     args = ap.parse_args()
+    if args.members_per_gpu is None:
+        args.members_per_gpu = 32 if args.workload == "ensemble4" else 8
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+        sys.exit(2)
     dist = None
     torch = None
     if world > 1 or args.force_dist:
@@ -244,14 +513,24 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == world
 
     import particlerobotsimulations_amd as pb
 
     if dist is None:
         pb.legacy.cudaInit(0, None)  # otherwise torch.cuda.set_device above already chose this rank's GPU
 
+    if args.workload != "arena":
+        run_ensemble_workload(args, rank, world, dist, torch)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     n = args.bots
     sim = make_sim(pb, n, args.pitch, seed=1 + rank)
+    cfg = sim.config()
+    assert cfg["force_variant"] == 2, cfg  # `value` is always the exact kernel
 
     def barrier():
         sim.synchronize()
@@ -292,6 +571,9 @@ def main():
         avg_launch_s = (dev_ms * 1e-3) / max(launches, 1)
         achieved = ALG_BYTES_PER_PARTICLE_STEP * n / avg_launch_s / 1e9
         tr = profiled_traffic() if n == 1_000_000 else None
+        clock_mhz, clock_span = (None, None)
+        if world == 1 and not args.no_clock:
+            clock_mhz, clock_span = measure_clock(pb, sim, min(args.steps, 2400), avg_launch_s * 1e3)
         out = {
             "metric": "particle-steps/sec at 10^6 bots; achieved HBM GB/s vs peak; 1/2/4/8-GPU ensemble",
             "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
@@ -301,42 +583,43 @@ def main():
                                    f"bots at pitch {args.pitch} (jammed and dense for the whole run), one light "
                                    "at (-230,0), 2048^2 grid, walls +-240, phase_std 0",
                        "bots_per_gpu": n, "dt": 0.01, "sort_interval": 180.0,
+                       "force_variant": cfg["force_variant"], "force_kind": cfg["force_kind"],
+                       "lanes_per_bot": cfg["lanes_per_bot"], "resident": cfg["resident"],
                        "parallelism": "single arena" if world == 1 else f"{world} independent arenas, one per GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                          "traffic_source": (f"profiles/latest_traffic.json ({tr['profile']}): {tr['method']}"
                                             if tr else None),
-                         "valu": ({k: tr[k] for k in ("valu_roofline_frac", "valu_time_us", "launch_us_unprofiled",
-                                                      "ns_simple", "ns_trans", "trans_per_wave",
-                                                      "valu_issue_share", "valu_insts_per_wave",
-                                                      "valu_lane_utilisation") if k in tr} if tr else None),
+                         "valu": valu_roofline(tr, n, avg_launch_s * 1e6, clock_mhz),
+                         "shader_clock_mhz": clock_mhz,
+                         "shader_clock_source": ("s_memtime / s_memrealtime of a sampler wave on its own stream beside "
+                                                 f"{clock_span:.2f} s more of the same steps (after the timed region)"
+                                                 if clock_mhz else None),
                          "kernel": "k_force<FUSE> (forces of step n + radius/integration of step n+1)",
                          "launches": launches, "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * n,
-                         "note": "the kernel is VALU-bound, not HBM-bound: ~50 neighbour pairs per bot, each "
-                                 "with 4 IEEE divisions and 2 IEEE square roots (DESIGN.md section 5).  `valu` "
-                                 "prices its instruction stream (PMC counts) at the issue rates tools/valu_rate "
-                                 "measures at 8 waves/SIMD: valu_roofline_frac is that VALU time over the launch time"},
+                         "note": "achieved/peak/frac are the HBM accounting SURVEY 8(d) prescribes (64 algorithmic "
+                                 "bytes per particle-step over the kernel's launch time); the kernel is VALU-issue "
+                                 "bound, not HBM bound (~50 neighbour pairs per bot, each with 4 IEEE divisions and 2 "
+                                 "IEEE square roots, DESIGN.md section 5): `valu` prices its instruction stream at the "
+                                 "datasheet issue rate at the measured shader clock and at tools/valu_rate's rates; "
+                                 "`traffic` (PMC) ~ algorithmic bytes, i.e. no wasted re-reads"},
             "device_ms_timed_region": dev_ms,
             "summaries_time_comx_comy": summaries,
         }
         sim.close()
+        if world == 1 and not args.no_large_arena:
+            out["large_arena"] = large_arena_leg(pb, args.pitch, 20, min(args.steps, 200))
         if world == 1 and not args.no_survey_literal:
             out["survey_literal_lattice"] = survey_literal(pb, n, args.steps, args.warmup)
         if world == 1 and not args.no_streamlined:
             out["streamlined"] = streamlined_leg(pb, n, args.pitch, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.pitch, args.cpu_seconds)
-        # the ONE JSON line goes last: push out whatever C libraries (RCCL's version banner) still hold
-        # in stdio buffers first
-        sys.stdout.flush()
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
+        emit(out)
+    else:
+        sim.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -146,6 +146,12 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
 int pbSimBatchSize(pbSim *sim, unsigned *nsims, unsigned *nbots);
 int pbSimSetStateOf(pbSim *sim, unsigned member, const float *pos, const float *vel, const float *rad,
                     const float *phase, const int *dead);
+/* The same for the bots [start, start + count) of the ORIGINAL order only (the arrays hold count
+ * entries); every other bot keeps its device state.  This is what Particlebot::setArray(array, data,
+ * start, count) needs once the simulation has stepped (particlebot.cpp:834-867 touches only that
+ * range). */
+int pbSimSetStateRangeOf(pbSim *sim, unsigned member, unsigned start, unsigned count, const float *pos,
+                         const float *vel, const float *rad, const float *phase, const int *dead);
 int pbSimGetStateOf(pbSim *sim, unsigned member, float *pos, float *vel, float *rad, float *phase, int *dead,
                     float *absForce_a, float *absForce_r);
 /* Exact checkpoints.  Between re-sorts the cell lists are STALE by design (the reference re-hashes
@@ -215,6 +221,30 @@ int pbSimSetLanesPerBot(pbSim *sim, int lanes);
  * picks it for a lone simulation of ~100 bots and for ensembles of many small ones),
  * 1 = never, 2 = whenever the simulation fits.  Results do not depend on it. */
 int pbSimSetResident(pbSim *sim, int mode);
+
+/* What the next pbSimStep will launch for this batch (after the automatic choices): the force variant
+ * as set and the kind of kernel that really runs (0-2 exact, 3 streamlined; 2 falls back to 1 when the
+ * constants are outside the fast forms' domain), the effective lanes per bot of the per-step kernel,
+ * whether the resident multi-step kernel is used, and the phase-noise generator.  bench.py echoes it
+ * into its JSON line so a reader can see which kernel a number belongs to. */
+typedef struct pbSimConfig {
+  int force_variant;
+  int force_kind;
+  int lanes_per_bot;
+  int resident;
+  int fast_math_ok;
+  int payload;
+  int rng; /* 0 PB-RNG v1 (default), 1 cuRAND-compatible XORWOW */
+} pbSimConfig;
+int pbSimGetConfig(pbSim *sim, pbSimConfig *cfg);
+
+/* Shader clock under load (diagnostic for the roofline report).  Begin launches ONE sleeping wave on
+ * a stream of its own that spans `seconds` of the 100 MHz real-time counter; End waits for it and
+ * returns shader cycles / real time in MHz over that span.  Run the workload in between: the figure
+ * is the clock the chip holds under THAT load (it lowers its clock under dense VALU work). */
+typedef struct pbClockSample pbClockSample;
+int pbClockSampleBegin(pbClockSample **out, double seconds);
+int pbClockSampleEnd(pbClockSample *sample, double *mhz, double *seconds_sampled);
 
 /* On-device check that the fast exact forms equal the compiler's IEEE sqrtf and division: every
  * float in the sqrt domain, and div_samples sampled (numerator, numerator, denominator) triples

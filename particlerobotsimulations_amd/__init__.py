@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import SimParams, make_params, pbSimStats  # noqa: F401
+from ._capi import SimParams, make_params, pbSimConfig, pbSimStats  # noqa: F401
 
 __all__ = ["Sim", "Ensemble", "DeviceArray", "legacy", "SimParams", "make_params", "library_paths", "self_test"]
 
@@ -123,6 +123,22 @@ class _Legacy:
 legacy = _Legacy()
 
 
+class ClockSample:
+    """Shader clock held while the enclosed work runs (pbClockSampleBegin/End): a sleeping wave on its
+    own stream spans `seconds` of real time; .mhz afterwards.  Diagnostic for the roofline report."""
+
+    def __init__(self, seconds):
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().pbClockSampleBegin(C.byref(self._h), float(seconds)), "pbClockSampleBegin")
+
+    def end(self):
+        mhz, sec = C.c_double(), C.c_double()
+        _capi.check(_capi.lib().pbClockSampleEnd(self._h, C.byref(mhz), C.byref(sec)), "pbClockSampleEnd")
+        self._h = None
+        self.mhz, self.seconds = mhz.value, sec.value
+        return self.mhz
+
+
 class Sim:
     """One resident simulation on the current GPU (pbSim* in include/particlebot_hip.h)."""
 
@@ -227,6 +243,13 @@ class Sim:
         s = pbSimStats()
         _capi.check(_capi.lib().pbSimGetStats(self._h, C.byref(s)))
         return {k: int(getattr(s, k)) for k, _ in pbSimStats._fields_}
+
+    def config(self):
+        """What the next step() launches: force_variant / force_kind / lanes_per_bot / resident /
+        fast_math_ok / payload / rng (pbSimGetConfig)."""
+        c = pbSimConfig()
+        _capi.check(_capi.lib().pbSimGetConfig(self._h, C.byref(c)))
+        return {k: int(getattr(c, k)) for k, _ in pbSimConfig._fields_}
 
     def set_force_variant(self, variant):
         """0/1/2: exact kernels (bit-identical to the oracle; 2 is the default).  3: streamlined

@@ -66,6 +66,11 @@ class pbSimStats(C.Structure):
                 ("resident_launches", C.c_ulonglong)]
 
 
+class pbSimConfig(C.Structure):
+    _fields_ = [("force_variant", C.c_int), ("force_kind", C.c_int), ("lanes_per_bot", C.c_int),
+                ("resident", C.c_int), ("fast_math_ok", C.c_int), ("payload", C.c_int), ("rng", C.c_int)]
+
+
 # every symbol include/particlebot_hip.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 _F = C.c_float
@@ -105,6 +110,7 @@ SYMBOLS = {
     "pbSimCreateBatch": (_I, [C.POINTER(_VP), C.POINTER(SimParams), _I, _F]),
     "pbSimBatchSize": (_I, [_VP, C.POINTER(_U), C.POINTER(_U)]),
     "pbSimSetStateOf": (_I, [_VP, _U, _VP, _VP, _VP, _VP, _VP]),
+    "pbSimSetStateRangeOf": (_I, [_VP, _U, _U, _U, _VP, _VP, _VP, _VP, _VP]),
     "pbSimGetStateOf": (_I, [_VP, _U] + [_VP] * 7),
     "pbSimCentroids": (_I, [_VP, C.POINTER(C.c_double)]),
     "pbSimGetLayoutOf": (_I, [_VP, _U, _VP, _VP, C.POINTER(_I)]),
@@ -125,6 +131,9 @@ SYMBOLS = {
     "pbSimSetForceVariant": (_I, [_VP, _I]),
     "pbSimSetLanesPerBot": (_I, [_VP, _I]),
     "pbSimSetResident": (_I, [_VP, _I]),
+    "pbSimGetConfig": (_I, [_VP, C.POINTER(pbSimConfig)]),
+    "pbClockSampleBegin": (_I, [C.POINTER(_VP), C.c_double]),
+    "pbClockSampleEnd": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pbSelfTest": (_I, [C.c_ulonglong] + [C.POINTER(C.c_ulonglong)] * 4),
 }
 

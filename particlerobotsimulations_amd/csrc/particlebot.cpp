@@ -414,7 +414,8 @@ void Particlebot::setArray(ParticlebotArray array, const float *data, int start,
     case POSITION:
       if (data != hPos + 2 * start) memcpy(hPos + 2 * start, data, sizeof(float) * 2 * count);
       if (fused) {
-        if (pbSimSetState(sim, hPos, nullptr, nullptr, nullptr, nullptr) != PB_OK) die("pbSimSetState");
+        if (pbSimSetStateRangeOf(sim, 0, (unsigned)start, (unsigned)count, data, nullptr, nullptr, nullptr, nullptr) != PB_OK)
+          die("pbSimSetStateRangeOf");
       } else {
         pbBufferSubData(posVbo, sizeof(float) * 2 * start, sizeof(float) * 2 * count, data);
       }
@@ -422,7 +423,8 @@ void Particlebot::setArray(ParticlebotArray array, const float *data, int start,
     case VELOCITY:
       if (data != hVel + 2 * start) memcpy(hVel + 2 * start, data, sizeof(float) * 2 * count);
       if (fused) {
-        if (pbSimSetState(sim, nullptr, hVel, nullptr, nullptr, nullptr) != PB_OK) die("pbSimSetState");
+        if (pbSimSetStateRangeOf(sim, 0, (unsigned)start, (unsigned)count, nullptr, data, nullptr, nullptr, nullptr) != PB_OK)
+          die("pbSimSetStateRangeOf");
       } else {
         copyArrayToDevice(dVel, data, (int)(start * 2 * sizeof(float)), (int)(count * 2 * sizeof(float)));
       }
@@ -430,7 +432,8 @@ void Particlebot::setArray(ParticlebotArray array, const float *data, int start,
     case PHASE:
       if (data != hphase + start) memcpy(hphase + start, data, sizeof(float) * count);
       if (fused) {
-        if (pbSimSetState(sim, nullptr, nullptr, nullptr, hphase, nullptr) != PB_OK) die("pbSimSetState");
+        if (pbSimSetStateRangeOf(sim, 0, (unsigned)start, (unsigned)count, nullptr, nullptr, nullptr, data, nullptr) != PB_OK)
+          die("pbSimSetStateRangeOf");
       } else {
         copyArrayToDevice(dphase, data, (int)(start * sizeof(float)), (int)(count * sizeof(float)));
       }
@@ -441,7 +444,8 @@ void Particlebot::setArray(ParticlebotArray array, const float *data, int start,
     case RADII:
       if (data != hRad + start) memcpy(hRad + start, data, sizeof(float) * count);
       if (fused) {
-        if (pbSimSetState(sim, nullptr, nullptr, hRad, nullptr, nullptr) != PB_OK) die("pbSimSetState");
+        if (pbSimSetStateRangeOf(sim, 0, (unsigned)start, (unsigned)count, nullptr, nullptr, data, nullptr, nullptr) != PB_OK)
+          die("pbSimSetStateRangeOf");
       } else {
         pbBufferSubData(radVbo, sizeof(float) * start, sizeof(float) * count, data);
       }

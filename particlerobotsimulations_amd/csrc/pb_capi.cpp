@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -305,6 +306,8 @@ struct Ensemble {
   std::vector<PbRunConfig *> cfgs;
   std::vector<Particlebot *> bots;
   pbSim *sim = nullptr;
+  bool haveRow = false;  // pbEnsembleRunSteps: a summary row has been written at time rowTime
+  float rowTime = 0.0f;
   ~Ensemble() {
     if (sim) pbSimDestroy(sim);
     for (auto *b : bots) delete b;
@@ -376,21 +379,25 @@ void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const
 
 void pbEnsembleDestroy(void *ev) { delete (Ensemble *)ev; }
 
-// Runs every member to max_time.  out: [nmembers][max_rows][4] floats (time, COMx, COMy, distance
-// of the COM to the light); *rows receives the number of rows written per member (the same for
-// all).  Returns the number of timesteps executed, or -1 on error.
-long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
+// Runs every member for up to max_steps timesteps (or to max_time, whichever comes first) and can be
+// called again to continue.  out: [nmembers][max_rows][4] floats (time, COMx, COMy, distance of the
+// COM to the light), one row whenever a dump row would be due (particlebot.cpp:309); *rows counts
+// the rows written per member so far (the same for all members) and is carried between calls.
+// Returns the number of timesteps executed by this call, or -1 on error.
+long pbEnsembleRunSteps(void *ev, long max_steps, float *out, int max_rows, int *rows) {
   Ensemble *e = (Ensemble *)ev;
   const int m = (int)e->bots.size();
   const PbRunConfig &c0 = *e->cfgs[0];
   const float dt = c0.timestep, di = c0.dump_interval;
   std::vector<double> com(2 * (size_t)m);
   long steps = 0;
-  int nrows = 0;
+  int nrows = rows ? *rows : 0;
   float t = 0.0f;
   if (pbSimGetTime(e->sim, &t) != PB_OK) return -1;
   for (;;) {
-    if (!(t - di * floorf(t / di) > 0.01f) && nrows < max_rows) {  // the dump test, particlebot.cpp:309
+    // a row is due at time t; e->rowTime remembers the last one written so that a call which stopped
+    // exactly at a dump time does not write it twice when the run is continued
+    if (out && !(t - di * floorf(t / di) > 0.01f) && nrows < max_rows && !(e->haveRow && e->rowTime == t)) {
       if (pbSimCentroids(e->sim, com.data()) != PB_OK) return -1;
       for (int k = 0; k < m; k++) {
         const SimParams &p = e->bots[k]->getParams();
@@ -402,8 +409,10 @@ long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
         row[3] = (float)sqrt(dx * dx + dy * dy);
       }
       nrows++;
+      e->haveRow = true;
+      e->rowTime = t;
     }
-    if (t > c0.params.max_time) break;
+    if (t > c0.params.max_time || steps >= max_steps) break;
     // host events at this step: dead-bot draws
     for (int k = 0; k < m; k++) {
       Particlebot *b = e->bots[k];
@@ -414,10 +423,11 @@ long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
       }
     }
     // run up to (not past) the next dump row or dead-bot draw of any member
-    int run = 1;
+    long run = 1;
     float tt = t + dt;
     for (;;) {
-      bool stop = !(tt - di * floorf(tt / di) > 0.01f) || tt > c0.params.max_time || run >= (1 << 20);
+      bool stop = !(tt - di * floorf(tt / di) > 0.01f) || tt > c0.params.max_time || run >= (1 << 20) ||
+                  steps + run >= max_steps;
       for (int k = 0; k < m && !stop; k++) {
         e->bots[k]->setHostTime(tt);
         stop = e->bots[k]->deadDrawDue(dt);
@@ -427,7 +437,7 @@ long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
       run++;
     }
     int done = 0;
-    if (pbSimStep(e->sim, dt, c0.sort_interval, run, &done) != PB_OK) return -1;
+    if (pbSimStep(e->sim, dt, c0.sort_interval, (int)run, &done) != PB_OK) return -1;
     steps += done;
     if (pbSimGetTime(e->sim, &t) != PB_OK) return -1;
     if (done == 0) break;
@@ -435,6 +445,16 @@ long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
   if (rows) *rows = nrows;
   return steps;
 }
+
+// Runs every member to max_time (the whole run in one call).
+long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
+  int nrows = 0;
+  const long steps = pbEnsembleRunSteps(ev, LONG_MAX, out, max_rows, &nrows);
+  if (rows) *rows = nrows;
+  return steps;
+}
+
+int pbEnsembleSynchronize(void *ev) { return pbSimSynchronize(((Ensemble *)ev)->sim); }
 
 int pbEnsembleGetState(void *ev, int member, float *pos, float *vel, float *rad) {
   Ensemble *e = (Ensemble *)ev;

@@ -799,31 +799,34 @@ __global__ __launch_bounds__(TILE) void k_phase(const PbDevParams *__restrict__ 
   phase[s] = ph;
 }
 
-// host arrays of ONE simulation (original order, staged on the device) -> slot order
+// host arrays of ONE simulation (original order, staged on the device) -> slot order.  The staged
+// arrays hold the bots [start, start + count) of the original order; other bots keep their state.
 __global__ __launch_bounds__(TILE) void k_set_state(const PbDevParams *__restrict__ params, uint32_t sim,
                                                     const uint32_t *__restrict__ orig, float4 *__restrict__ pr,
                                                     float2 *__restrict__ vel, float *__restrict__ phase,
                                                     int *__restrict__ dead, const float2 *__restrict__ inPos,
                                                     const float2 *__restrict__ inVel, const float *__restrict__ inRad,
                                                     const float *__restrict__ inPhase, const int *__restrict__ inDead,
-                                                    uint32_t n) {
+                                                    uint32_t n, uint32_t start, uint32_t count) {
   const PbDevParams &P = params[sim];
   const uint32_t l = blockIdx.x * TILE + threadIdx.x;
   if (l >= n) return;
   const uint32_t s = sim * n + l;
   const uint32_t o = orig[s];
+  const uint32_t k = o - start;  // index into the staged arrays
+  const bool mine = k < count;
   float4 q = pr[s];
-  if (inPos) {
-    const float2 p = inPos[o];
+  if (inPos && mine) {
+    const float2 p = inPos[k];
     q.x = p.x;
     q.y = p.y;
   }
-  if (inRad) q.z = inRad[o];
+  if (inRad && mine) q.z = inRad[k];
   q.w = (P.nDead == -1 && o == P.nCells - 1u) ? P.attractionFactor : 1.0f;
   pr[s] = q;
-  if (inVel) vel[s] = inVel[o];
-  if (inPhase) phase[s] = inPhase[o];
-  if (inDead) dead[s] = inDead[o];
+  if (inVel && mine) vel[s] = inVel[k];
+  if (inPhase && mine) phase[s] = inPhase[k];
+  if (inDead && mine) dead[s] = inDead[k];
 }
 
 // slot order -> original order, ONE simulation
@@ -980,6 +983,24 @@ __global__ __launch_bounds__(256) void k_selftest_div(unsigned long long samples
   if (seen) atomicAdd(checked, seen);
 }
 
+// ---- shader-clock sampler (diagnostic) ---------------------------------------------------------
+// ONE wave that sleeps for `ticks` of the 100 MHz real-time counter and reports how many shader
+// cycles (s_memtime) went by meanwhile: launched on its own stream beside the force kernels it reads
+// the clock the chip actually holds under that load (MI355X_MICROARCH.md, DVFS give-back item 6).
+__global__ __launch_bounds__(64) void k_clock_sample(unsigned long long ticks, unsigned long long *__restrict__ out) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long r = r0;
+  while (r - r0 < ticks) {
+    __builtin_amdgcn_s_sleep(64);
+    r = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  out[0] = c1 - c0;
+  out[1] = r - r0;
+}
+
 }  // namespace
 
 // ---- the object -----------------------------------------------------------------------------
@@ -1022,7 +1043,8 @@ struct pbSim {
   bool payload = false, fastOk = false;
   int variant = 2;  // force kernel: 0 reference-shaped branches, 1 branch-free, 2 (default) + fast exact math
   int resident = 0;     // 0 automatic, 1 never, 2 whenever the simulation fits one workgroup (n <= 1024)
-  int lanesPerBot = 0;  // lanes per bot of the per-step force kernel: 0 automatic; 1 (throughput form), 2, 4, 8
+  int lanesPerBot = 0;  // lanes per bot of the per-step force kernel: 0 automatic; 1 (throughput form), 2, 4, 8, 16
+  int rng = 0;          // phase noise: 0 PB-RNG v1 (counter based), 1 cuRAND-compatible XORWOW (pb_xorwow.hpp)
   pbSimStats stats{};
 };
 
@@ -1046,11 +1068,46 @@ void launchForceT(pbSim *S, int c, int o, float dt, float tNext, int doRadiusNex
                      S->cellS, S->n, dt, tNext, doRadiusNext, perXcd);
 }
 
-void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext) {
-  const bool payload = S->payload;
+// What a per-step force launch of this batch will be: the streamlined kernel or an exact one
+// (kind 0 reference-shaped branches, 1 branch-free, 2 branch-free + fast exact math), and the lanes
+// per bot of the exact branch-free kernels.  One place decides, so pbSimGetConfig reports what runs.
+struct PbForcePlan {
+  bool stream;
+  int kind;
+  int form;  // lanes per bot (1 = throughput form)
+};
+
+PbForcePlan forcePlan(const pbSim *S) {
+  PbForcePlan p{false, 0, 1};
   if (S->variant == 3 && S->total < (1u << 28) - 4u &&  // (32-bit byte offsets into posrad)
       (S->lanesPerBot == 1 || (S->lanesPerBot == 0 && S->total > 131072u))) {
     // streamlined arithmetic: throughput form only (smaller batches use the exact forms below)
+    p.stream = true;
+    p.kind = 3;
+    return p;
+  }
+  // variant 0: reference-shaped branches; 1: branch-free; 2 (default): branch-free + fast exact math
+  p.kind = S->variant == 0 ? 0 : (S->variant == 1 || !S->fastOk) ? 1 : 2;
+  // A per-step launch of a small or medium batch is bound by one wave's serial neighbour loop, not
+  // by VALU throughput, so bots get L = 8 or 4 lanes each while the chip has lanes to spare
+  // (measured on MI355X, one simulation on the bench lattice, us/step for L = 1/2/4/8:
+  //  3x10^4 bots 25/18/13/12, 6x10^4 28/21/18.5/20, 10^5 32/26/25.7/29, 2x10^5 35/40/42/49;
+  //  L = 8 vs 16: 300 bots 6.4/5.7, 4000 bots 7.0/6.0, 10^4 bots 7.8/8.0).
+  // Only the branch-free kernels have the multi-lane forms.
+  if (p.kind != 0) {
+    const int want = S->lanesPerBot;
+    if (want == 16 || (want == 0 && S->total <= 8192u)) p.form = 16;
+    else if (want == 8 || (want == 0 && S->total <= 49152u)) p.form = 8;
+    else if (want == 4 || (want == 0 && S->total <= 131072u)) p.form = 4;
+    else if (want == 2) p.form = 2;
+  }
+  return p;
+}
+
+void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext) {
+  const bool payload = S->payload;
+  const PbForcePlan plan = forcePlan(S);
+  if (plan.stream) {
     const uint32_t tiles = cdiv(S->n, TILE);
     const uint32_t perXcd = tiles >= 64u ? cdiv(tiles, 8u) : 0u;
     const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
@@ -1065,22 +1122,7 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
 #undef PB_STREAM
     return;
   }
-  // variant 0: reference-shaped branches; 1: branch-free; 2 (default): branch-free + fast exact math
-  const int kind = S->variant == 0 ? 0 : (S->variant == 1 || !S->fastOk) ? 1 : 2;
-  // A per-step launch of a small or medium batch is bound by one wave's serial neighbour loop, not
-  // by VALU throughput, so bots get L = 8 or 4 lanes each while the chip has lanes to spare
-  // (measured on MI355X, one simulation on the bench lattice, us/step for L = 1/2/4/8:
-  //  3x10^4 bots 25/18/13/12, 6x10^4 28/21/18.5/20, 10^5 32/26/25.7/29, 2x10^5 35/40/42/49;
-  //  L = 8 vs 16: 300 bots 6.4/5.7, 4000 bots 7.0/6.0, 10^4 bots 7.8/8.0).
-  // Only the branch-free kernels have the multi-lane forms.
-  int form = 0;
-  if (kind != 0) {
-    const int want = S->lanesPerBot;
-    if (want == 16 || (want == 0 && S->total <= 8192u)) form = 16;
-    else if (want == 8 || (want == 0 && S->total <= 49152u)) form = 8;
-    else if (want == 4 || (want == 0 && S->total <= 131072u)) form = 4;
-    else if (want == 2) form = 2;
-  }
+  const int kind = plan.kind, form = plan.form;
 #define PB_CASE(F, PL, K, FL, FA)                                                                        \
   if (fuse == F && payload == PL && kind == K) {                                                         \
     if (FL && form == 16) return launchForceT<F, PL, FL, FA, (FL ? 16 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
@@ -1360,6 +1402,10 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     g_lastError = "pbSimCreateBatch: batch too large (at most 2^28 bots and 2^32 cells in one batch)";
     return PB_ERR_ARG;
   }
+  if (nsims > 65535) {  // members ride in gridDim.y
+    g_lastError = "pbSimCreateBatch: at most 65535 simulations in one batch";
+    return PB_ERR_ARG;
+  }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
     g_lastError = "pbSimCreate: no HIP device visible";
@@ -1379,9 +1425,19 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     pbFlattenParams(S->hP[k], params[k], wallHalf);
     S->fastOk = S->fastOk && pbFastMathAllowed(S->hP[k]);
   }
-  if (const char *v = getenv("PB_FORCE_VARIANT")) S->variant = atoi(v);  // A/B switches for benchmarking
-  if (const char *v = getenv("PB_LANES_PER_BOT")) S->lanesPerBot = atoi(v);
-  if (const char *v = getenv("PB_RESIDENT")) S->resident = atoi(v);
+  // A/B switches for tools/ab_bench.py: honoured only under PB_ALLOW_ENV_OVERRIDES=1 and through the
+  // same range checks as the setters, so a stray variable cannot silently change what a caller runs
+  if (const char *allow = getenv("PB_ALLOW_ENV_OVERRIDES"); allow && atoi(allow) == 1) {
+    int rc = PB_OK;
+    if (const char *v = getenv("PB_FORCE_VARIANT")) rc |= pbSimSetForceVariant(S, atoi(v));
+    if (const char *v = getenv("PB_LANES_PER_BOT")) rc |= pbSimSetLanesPerBot(S, atoi(v));
+    if (const char *v = getenv("PB_RESIDENT")) rc |= pbSimSetResident(S, atoi(v));
+    if (rc != PB_OK) {
+      g_lastError = "pbSimCreateBatch: PB_FORCE_VARIANT / PB_LANES_PER_BOT / PB_RESIDENT out of range";
+      delete S;
+      return PB_ERR_ARG;
+    }
+  }
   const size_t n = S->n, total = S->total, G1 = (size_t)S->hP[0].numCells + 1;
 #define PB_TRY_NEW(expr)                                             \
   do {                                                               \
@@ -1432,7 +1488,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   for (uint32_t k = 0; k < S->nsims; k++)
     hipLaunchKernelGGL(k_set_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->dP, k, S->orig[0], S->pr[0],
                        S->vel[0], S->phase[0], S->dead[0], (const float2 *)nullptr, (const float2 *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, (const int *)nullptr, S->n);
+                       (const float *)nullptr, (const float *)nullptr, (const int *)nullptr, S->n, 0u, S->n);
   PB_TRY_NEW(hipGetLastError());
   PB_TRY_NEW(hipStreamSynchronize(S->stream));
 #undef PB_TRY_NEW
@@ -1451,26 +1507,37 @@ int pbSimBatchSize(pbSim *S, unsigned *nsims, unsigned *nbots) {
   return PB_OK;
 }
 
-int pbSimSetStateOf(pbSim *S, unsigned sim, const float *pos, const float *vel, const float *rad,
-                    const float *phase, const int *dead) {
+int pbSimSetStateRangeOf(pbSim *S, unsigned sim, unsigned start, unsigned count, const float *pos,
+                         const float *vel, const float *rad, const float *phase, const int *dead) {
   if (!S || sim >= S->nsims) return PB_ERR_ARG;
-  const size_t n = S->n;
+  if (start > S->n || count > S->n - start) {
+    g_lastError = "pbSimSetStateRangeOf: [start, start + count) must lie inside the simulation's bots";
+    return PB_ERR_ARG;
+  }
+  if (count == 0) return PB_OK;
+  const size_t n = S->n, m = count;
   char *st = S->stage;
   float2 *dPos = (float2 *)st, *dVel = (float2 *)(st + 8 * n);
   float *dRad = (float *)(st + 16 * n), *dPhase = (float *)(st + 20 * n);
   int *dDead = (int *)(st + 24 * n);
-  if (pos) PB_TRY(hipMemcpyAsync(dPos, pos, 8 * n, hipMemcpyHostToDevice, S->stream));
-  if (vel) PB_TRY(hipMemcpyAsync(dVel, vel, 8 * n, hipMemcpyHostToDevice, S->stream));
-  if (rad) PB_TRY(hipMemcpyAsync(dRad, rad, 4 * n, hipMemcpyHostToDevice, S->stream));
-  if (phase) PB_TRY(hipMemcpyAsync(dPhase, phase, 4 * n, hipMemcpyHostToDevice, S->stream));
-  if (dead) PB_TRY(hipMemcpyAsync(dDead, dead, 4 * n, hipMemcpyHostToDevice, S->stream));
+  if (pos) PB_TRY(hipMemcpyAsync(dPos, pos, 8 * m, hipMemcpyHostToDevice, S->stream));
+  if (vel) PB_TRY(hipMemcpyAsync(dVel, vel, 8 * m, hipMemcpyHostToDevice, S->stream));
+  if (rad) PB_TRY(hipMemcpyAsync(dRad, rad, 4 * m, hipMemcpyHostToDevice, S->stream));
+  if (phase) PB_TRY(hipMemcpyAsync(dPhase, phase, 4 * m, hipMemcpyHostToDevice, S->stream));
+  if (dead) PB_TRY(hipMemcpyAsync(dDead, dead, 4 * m, hipMemcpyHostToDevice, S->stream));
   const int c = S->cur;
   hipLaunchKernelGGL(k_set_state, dim3(cdiv(S->n, TILE)), dim3(TILE), 0, S->stream, S->dP, sim, S->orig[c],
                      S->pr[c], S->vel[c], S->phase[c], S->dead[c], pos ? dPos : nullptr, vel ? dVel : nullptr,
-                     rad ? dRad : nullptr, phase ? dPhase : nullptr, dead ? dDead : nullptr, S->n);
+                     rad ? dRad : nullptr, phase ? dPhase : nullptr, dead ? dDead : nullptr, S->n, start, count);
   PB_TRY(hipGetLastError());
   PB_TRY(hipStreamSynchronize(S->stream));
   return PB_OK;
+}
+
+int pbSimSetStateOf(pbSim *S, unsigned sim, const float *pos, const float *vel, const float *rad,
+                    const float *phase, const int *dead) {
+  if (!S) return PB_ERR_ARG;
+  return pbSimSetStateRangeOf(S, sim, 0u, S->n, pos, vel, rad, phase, dead);
 }
 
 int pbSimSetState(pbSim *S, const float *pos, const float *vel, const float *rad, const float *phase,
@@ -1697,6 +1764,56 @@ int pbSelfTest(unsigned long long div_samples, unsigned long long *sqrt_checked,
   if (sqrt_mismatches) *sqrt_mismatches = h[1];
   if (div_checked) *div_checked = h[2];
   if (div_mismatches) *div_mismatches = h[3];
+  return PB_OK;
+}
+
+int pbSimGetConfig(pbSim *S, pbSimConfig *cfg) {
+  if (!S || !cfg) return PB_ERR_ARG;
+  const PbForcePlan p = forcePlan(S);
+  cfg->force_variant = S->variant;
+  cfg->force_kind = p.kind;
+  cfg->lanes_per_bot = p.form;
+  cfg->resident = residentWanted(S) ? 1 : 0;
+  cfg->fast_math_ok = S->fastOk ? 1 : 0;
+  cfg->payload = S->payload ? 1 : 0;
+  cfg->rng = S->rng;
+  return PB_OK;
+}
+
+struct pbClockSample {
+  hipStream_t stream = nullptr;
+  unsigned long long *dev = nullptr;
+};
+
+int pbClockSampleBegin(pbClockSample **out, double seconds) {
+  if (!out || !(seconds > 0.0) || seconds > 30.0) return PB_ERR_ARG;
+  pbClockSample *h = new pbClockSample();
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void **)&h->dev, 2 * sizeof(unsigned long long)) != hipSuccess) {
+    g_lastError = "pbClockSampleBegin: stream/buffer creation failed";
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PB_ERR_HIP;
+  }
+  hipLaunchKernelGGL(k_clock_sample, dim3(1), dim3(64), 0, h->stream, (unsigned long long)(seconds * 1e8), h->dev);
+  *out = h;
+  return PB_OK;
+}
+
+int pbClockSampleEnd(pbClockSample *h, double *mhz, double *seconds_sampled) {
+  if (!h) return PB_ERR_ARG;
+  unsigned long long v[2] = {0, 0};
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(v, h->dev, sizeof v, hipMemcpyDeviceToHost);
+  (void)hipFree(h->dev);
+  (void)hipStreamDestroy(h->stream);
+  delete h;
+  if (e != hipSuccess || v[1] == 0) {
+    g_lastError = "pbClockSampleEnd: sampler kernel failed";
+    return PB_ERR_HIP;
+  }
+  if (mhz) *mhz = (double)v[0] / (double)v[1] * 100.0;
+  if (seconds_sampled) *seconds_sampled = (double)v[1] * 1e-8;
   return PB_OK;
 }
 

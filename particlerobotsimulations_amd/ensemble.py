@@ -33,47 +33,100 @@ def member_overrides(k, seed0=0, sweep=None):
     return text
 
 
+class LocalEnsemble:
+    """The members this rank runs, as ONE batched pbSim on the current GPU (pbEnsemble* in
+    csrc/pb_capi.cpp): placement and dead-bot draws on the host from each member's own stream, one
+    kernel launch per timestep for the whole batch, summary rows whenever a dump row is due."""
+
+    def __init__(self, cfg_path, overrides_per_member, common=None, max_rows=4096):
+        from . import host
+        L = host.lib()
+        L.pbEnsembleCreate.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
+        L.pbEnsembleCreate.restype = C.c_void_p
+        L.pbEnsembleDestroy.argtypes = [C.c_void_p]
+        L.pbEnsembleRun.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.pbEnsembleRun.restype = C.c_long
+        L.pbEnsembleRunSteps.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.pbEnsembleRunSteps.restype = C.c_long
+        L.pbEnsembleSynchronize.argtypes = [C.c_void_p]
+        L.pbEnsembleNumBots.argtypes = [C.c_void_p]
+        L.pbEnsembleNumBots.restype = C.c_uint
+        L.pbEnsembleGetState.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._L = L
+        self.m = len(overrides_per_member)
+        self.max_rows = max_rows
+        self._h = None
+        self._rows = C.c_int(0)
+        self.out = np.zeros((self.m, max_rows, 4), np.float32)
+        if self.m == 0:
+            return
+        arr = (C.c_char_p * self.m)(*[o.encode() for o in overrides_per_member])
+        common_b = "\n".join(f"{k}\n{v}" for k, v in (common or {}).items()).encode() or None
+        self._h = L.pbEnsembleCreate(os.fsencode(cfg_path), common_b, arr, self.m)
+        if not self._h:
+            raise RuntimeError("pbEnsembleCreate failed")
+        self.n = int(L.pbEnsembleNumBots(self._h))
+
+    def run_steps(self, max_steps):
+        """Up to max_steps timesteps of every member (stops at max_time); returns the number run."""
+        if self._h is None:
+            return 0
+        steps = self._L.pbEnsembleRunSteps(self._h, int(max_steps), self.out.ctypes.data_as(C.c_void_p),
+                                           self.max_rows, C.byref(self._rows))
+        if steps < 0:
+            raise RuntimeError("pbEnsembleRunSteps failed")
+        return int(steps)
+
+    def run(self):
+        """To max_time."""
+        return self.run_steps(2 ** 62)
+
+    def synchronize(self):
+        if self._h is not None:
+            self._L.pbEnsembleSynchronize(self._h)
+
+    @property
+    def rows(self):
+        """[members, rows written so far, 4] = (time, COMx, COMy, distance of the COM to the light)."""
+        return self.out[:, :self._rows.value].copy()
+
+    def final_states(self):
+        states = []
+        for k in range(self.m):
+            st = {"pos": np.empty((self.n, 2), np.float32), "vel": np.empty((self.n, 2), np.float32),
+                  "rad": np.empty(self.n, np.float32)}
+            if self._L.pbEnsembleGetState(self._h, k, *[st[x].ctypes.data_as(C.c_void_p)
+                                                        for x in ("pos", "vel", "rad")]):
+                raise RuntimeError("pbEnsembleGetState failed")
+            states.append(st)
+        return states
+
+    def close(self):
+        if self._h is not None:
+            self._L.pbEnsembleDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def run_local(cfg_path, overrides_per_member, common=None, max_rows=4096, final_state=False):
     """Run the given members (a list of override strings) as one batch on the current GPU.
     Returns (rows[m, r, 4] float32, steps), plus a list of per-member dicts (pos, vel, rad at the
     end of the run) when final_state is set."""
-    from . import host
-    L = host.lib()
-    L.pbEnsembleCreate.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
-    L.pbEnsembleCreate.restype = C.c_void_p
-    L.pbEnsembleDestroy.argtypes = [C.c_void_p]
-    L.pbEnsembleRun.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
-    L.pbEnsembleRun.restype = C.c_long
-    m = len(overrides_per_member)
-    if m == 0:
+    if len(overrides_per_member) == 0:
         return np.zeros((0, 0, 4), np.float32), 0
-    arr = (C.c_char_p * m)(*[o.encode() for o in overrides_per_member])
-    common_b = "\n".join(f"{k}\n{v}" for k, v in (common or {}).items()).encode() or None
-    h = L.pbEnsembleCreate(os.fsencode(cfg_path), common_b, arr, m)
-    if not h:
-        raise RuntimeError("pbEnsembleCreate failed")
+    e = LocalEnsemble(cfg_path, overrides_per_member, common, max_rows)
     try:
-        out = np.zeros((m, max_rows, 4), np.float32)
-        rows = C.c_int()
-        steps = L.pbEnsembleRun(h, out.ctypes.data_as(C.c_void_p), max_rows, C.byref(rows))
-        if steps < 0:
-            raise RuntimeError("pbEnsembleRun failed")
+        steps = e.run()
         if final_state:
-            L.pbEnsembleNumBots.argtypes = [C.c_void_p]
-            L.pbEnsembleNumBots.restype = C.c_uint
-            L.pbEnsembleGetState.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-            n = L.pbEnsembleNumBots(h)
-            states = []
-            for k in range(m):
-                st = {"pos": np.empty((n, 2), np.float32), "vel": np.empty((n, 2), np.float32),
-                      "rad": np.empty(n, np.float32)}
-                if L.pbEnsembleGetState(h, k, *[st[x].ctypes.data_as(C.c_void_p) for x in ("pos", "vel", "rad")]):
-                    raise RuntimeError("pbEnsembleGetState failed")
-                states.append(st)
-            return out[:, :rows.value].copy(), int(steps), states
-        return out[:, :rows.value].copy(), int(steps)
+            return e.rows, steps, e.final_states()
+        return e.rows, steps
     finally:
-        L.pbEnsembleDestroy(h)
+        e.close()
 
 
 def gather_summaries(local_rows, n_members, rank, world, dist=None, device="cpu"):

@@ -1,0 +1,134 @@
+"""GPU parity of the BASELINE.json configurations that had no `-m gpu` oracle test of their own
+(VERDICT round 1): the bench headline workload itself (configs[2]: 10^6 bots, SQUARE lattice,
+bench.workload_params), config 4 (example_obstacle.cfg / example_object_transport.cfg as batched
+seed ensembles through pbEnsembleRun) and config 5 at member level (example_dead_cells.cfg scaled to
+10^5 bots with 0 / 20 % / 40 % dead).  Everything is compared with the CPU oracle BIT FOR BIT on
+the state arrays; summary rows (double-precision on-device centroid) within 1e-6 of the oracle's
+positions averaged in float64."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_bit_equal, simparams_from_orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = lambda name: os.path.join(ROOT, "examples", name)
+STATE_KEYS = ("pos", "vel", "rad", "phase", "absForce_a", "absForce_r")
+
+
+def dump_due(t, di):
+    """particlebot.cpp:309-310 in fp32: a row is written unless t - di*floor(t/di) > 0.01f."""
+    f = np.float32
+    t, di = f(t), f(di)
+    return not (f(t - f(di * f(np.floor(f(t / di))))) > f(0.01))
+
+
+def oracle_member(orc, cfg, over, di):
+    """display() loop (main.cpp:354-361) of one ensemble member on the oracle: summary rows
+    (t, COMx, COMy, distance of the COM to the light) at every dump time, then the final state."""
+    P = orc.load_cfg(cfg, **over)
+    sim = orc.Sim(P)
+    rows = []
+    while True:
+        if dump_due(sim.time, di):
+            c = sim.view("pos").astype(np.float64).mean(0)
+            rows.append((sim.time, c[0], c[1], np.hypot(c[0] - P.light_x, c[1] - P.light_y)))
+        if sim.update():
+            break
+    return np.array(rows), sim
+
+
+def test_bench_headline_workload_matches_oracle(orc):
+    """bench.py's `value` workload, exactly as bench.make_sim builds it (10^6 bots on the square
+    lattice at pitch 0.155, 2048^2 grid, walls +-240, force variant 2 pinned), for 32 steps from
+    t = 0: the step-0 phase update and sort, the un-fused first step and 31 fused launches.  Every
+    state array equals the oracle's bit for bit at steps 1, 12 and 32."""
+    import bench
+    import particlerobotsimulations_amd as pb
+    pb.legacy.cudaInit(0, None)
+    n = 1_000_000
+    P = orc.default_params(nCells=n, nDead=0, seed=1, phase_std=0.0, max_time=1e9, light_x=-230.0, light_y=0.0,
+                           grid=2048, arena_half=240.0)
+    # the oracle's parameter block is the bench's
+    sp_bench, _k1 = bench.workload_params(n, seed=1)
+    sp_orc, _k2 = simparams_from_orc(P)
+    for name in ("nCells", "nDead", "gravity", "spring", "damping", "shear", "attraction", "friction", "min_radius",
+                 "max_radius", "rise_period", "light_x", "light_y", "phase_std", "numCells", "Nx", "constraint"):
+        assert getattr(sp_bench, name) == getattr(sp_orc, name), name
+    assert tuple(sp_bench.gridSize) == tuple(sp_orc.gridSize) and tuple(sp_bench.cellSize) == tuple(sp_orc.cellSize)
+    assert tuple(sp_bench.worldOrigin) == tuple(sp_orc.worldOrigin)
+    gsim = bench.make_sim(pb, n, bench.LATTICE_PITCH, seed=1)
+    assert gsim.config()["force_variant"] == 2 and gsim.config()["lanes_per_bot"] == 1
+    orc.lib().orc_set_num_threads(orc.usable_cpus())
+    osim = orc.Sim(P, reset=True, hex=True)
+    osim.set("pos", bench.square_lattice(n, bench.LATTICE_PITCH))
+    done = 0
+    for upto in (1, 12, 32):
+        gsim.step(upto - done)
+        osim.run(upto - done)
+        done = upto
+        st = gsim.get_state()
+        for key in STATE_KEYS:
+            assert_bit_equal(st[key], osim.get(key), f"bench workload, step {done}: {key}")
+        assert gsim.time == osim.time
+    # the lattice is in contact everywhere: a dense, jammed workload (not a dilute gas)
+    assert (st["absForce_r"] > 0).mean() > 0.99
+    s = gsim.stats()
+    assert s["resorts"] == 1 and s["fused_launches"] >= 29
+    gsim.close()
+    osim.close()
+
+
+@pytest.mark.parametrize("cfg,max_time,di", [("example_obstacle.cfg", "12.6", "6"),
+                                             ("example_object_transport.cfg", "12.6", "6")])
+def test_config4_seed_ensembles_match_oracle(orc, cfg, max_time, di):
+    """BASELINE config 4: the obstacle course (500 bots, 3 circles) and the object transport (200
+    bots + payload) as 16-seed Monte-Carlo batches through pbEnsembleRun -- random placement from
+    each member's own libc stream, phase noise (phase_std 0.6) at t = 0 and t = 12, 1260 steps --
+    against 16 stand-alone oracle runs: 3 summary rows each and the final state bit for bit."""
+    from particlerobotsimulations_amd import ensemble
+    seeds = [1000 + k for k in range(16)]
+    common = {"max_time": max_time, "dump_interval": di}
+    rows, steps, states = ensemble.run_local(EX(cfg), [f"seed\n{s}" for s in seeds], common, final_state=True)
+    assert rows.shape[0] == 16 and rows.shape[1] == 3 and steps == 1261, (rows.shape, steps)
+    for k, s in enumerate(seeds):
+        orows, osim = oracle_member(orc, EX(cfg), dict(seed=s, max_time=float(max_time), dump_interval=float(di)),
+                                    float(di))
+        assert orows.shape == (3, 4)
+        assert np.array_equal(orows[:, 0].astype(np.float32), rows[k, :, 0]), (k, orows[:, 0], rows[k, :, 0])
+        assert np.abs(orows[:, 1:] - rows[k, :, 1:]).max() < 2e-6, (k, orows, rows[k])
+        for key in ("pos", "vel", "rad"):
+            assert_bit_equal(states[k][key], osim.get(key), f"{cfg} seed {s}: {key}")
+        osim.close()
+    # sixteen different blobs
+    assert len({tuple(np.round(r[-1, 1:3], 5)) for r in rows}) == 16
+
+
+def test_config5_dead_fraction_members_match_oracle(orc):
+    """BASELINE config 5 at member level: example_dead_cells.cfg scaled to 10^5 bots, light moved
+    outside the blob to (-40, 0), dead fractions 0 / 20 % / 40 % (one seed each) as ONE batch --
+    the reference's random placement of 10^5 bots, the dead-bot draw at t = 0 from each member's own
+    stream, noise, 106 steps of the batched engine -- against three stand-alone oracle runs."""
+    from particlerobotsimulations_amd import ensemble
+    cfg = EX("example_dead_cells.cfg")
+    common = {"nCells": "100000", "light_x": "-40", "light_y": "0", "max_time": "1.05", "dump_interval": "0.5"}
+    members = [(0, 4001), (20000, 4002), (40000, 4003)]
+    rows, steps, states = ensemble.run_local(cfg, [f"seed\n{s}\nnDead\n{d}" for d, s in members], common,
+                                             final_state=True)
+    assert rows.shape[:2] == (3, 3) and steps >= 106, (rows.shape, steps)
+    orc.lib().orc_set_num_threads(orc.usable_cpus())
+    for k, (nd, s) in enumerate(members):
+        orows, osim = oracle_member(orc, cfg, dict(nCells=100000, nDead=nd, seed=s, light_x=-40.0, light_y=0.0,
+                                                   max_time=1.05, dump_interval=0.5), 0.5)
+        assert int(osim.get("dead").sum()) == nd
+        assert np.array_equal(orows[:, 0].astype(np.float32), rows[k, :, 0])
+        assert np.abs(orows[:, 1:] - rows[k, :, 1:]).max() < 2e-6, (k, orows, rows[k])
+        for key in ("pos", "vel", "rad"):
+            assert_bit_equal(states[k][key], osim.get(key), f"dead fraction {nd}/100000: {key}")
+        # dead bots never actuate: their radius is still the placement radius
+        dead = osim.get("dead") != 0
+        assert np.all(states[k]["rad"][dead] == np.float32(osim.P.min_radius))
+        osim.close()

@@ -25,7 +25,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["unit"] == "particle-steps/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # achieved/peak/frac are the HBM accounting of SURVEY 8(d); `bound` names what really binds the kernel
+    assert r["bound"] == "valu" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert d["config"]["force_variant"] == 2 and d["config"]["lanes_per_bot"] in (1, 4) and d["config"]["resident"] == 0
+    assert 500.0 < r["shader_clock_mhz"] < 2600.0, r["shader_clock_mhz"]
+    la = d["large_arena"]
+    assert la["bots"] == 8_000_000 and la["finite_at_end"] and la["us_per_step"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert abs(d["value"] - 200000 * 60 / (d["ms_per_step"] * 60 * 1e-3)) / d["value"] < 1e-6
     c = d["cpu_baseline"]

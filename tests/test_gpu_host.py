@@ -140,6 +140,34 @@ def test_set_get_array(host):
     assert_bit_equal(s.get("rad"), rad, "rad")
 
 
+@pytest.mark.parametrize("engine", ["fused", "legacy"])
+def test_set_array_subrange_after_stepping_leaves_other_bots_alone(host, engine):
+    """setArray(array, data, start, count) on a simulation that has already stepped touches only the
+    bots [start, start + count) (particlebot.cpp:834-867): every other bot keeps its CURRENT device
+    state, not a stale host copy."""
+    s = host.HostSim(EX("example_dead_cells.cfg"), engine=engine, max_time="1e9")
+    s.advance(150)                      # through a re-sort: slot order != original order
+    before = {k: s.get(k) for k in ("pos", "vel", "rad", "phase")}
+    assert np.abs(before["vel"]).max() > 0
+    new_pos = before["pos"][40:43] + np.float32(0.25)
+    new_vel = np.full((1, 2), 0.5, np.float32)
+    new_rad = np.full(5, 0.1, np.float32)
+    new_phase = np.full(2, -1.5, np.float32)
+    s.set("pos", new_pos, start=40)
+    s.set("vel", new_vel, start=7)
+    s.set("rad", new_rad, start=95)
+    s.set("phase", new_phase, start=0)
+    want = {k: v.copy() for k, v in before.items()}
+    want["pos"][40:43] = new_pos
+    want["vel"][7:8] = new_vel
+    want["rad"][95:100] = new_rad
+    want["phase"][0:2] = new_phase
+    for k in want:
+        assert_bit_equal(s.get(k), want[k], f"{engine}: {k} after ranged setArray")
+    s.advance(10)                       # and the simulation carries on from there
+    assert np.isfinite(s.get("pos")).all()
+
+
 def test_headless_runner_binary(orc, tmp_path):
     """particlebot_run <cfg>: the reference's main() minus the window, end to end."""
     exe = os.path.join(ROOT, "particlerobotsimulations_amd", "bin", "particlebot_run")

@@ -35,9 +35,9 @@ def main():
            else bench.hex_lattice(n, np.float32(args.pitch)))
     sims = {}
     for v in variants:
-        os.environ["PB_FORCE_VARIANT"] = str(v)
         sp, keep = bench.workload_params(n, seed=1)
         s = pb.Sim(sp, wall_half=240.0, keepalive=keep)
+        s.set_force_variant(v)
         s.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
                     phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
         s.step(args.skip)

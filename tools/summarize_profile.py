@@ -63,7 +63,10 @@ def valu_roofline(root, d, avg_ns_profiled, simds=1024):
     valu, trans = d["SQ_INSTS_VALU"], d["SQ_INSTS_VALU_TRANS_F32"]
     valu_ns = ((valu - trans) * ns_simple + trans * ns_trans) / simds
     launch_us = bench["roofline"]["avg_launch_us"]
+    mhz = rates.get("in_kernel_mhz")
     return {"valu_roofline_frac": valu_ns / 1e3 / launch_us, "valu_time_us": valu_ns / 1e3,
+            "valu_rate_mhz": (sum(mhz.values()) / len(mhz)) if mhz else None,
+            "valu_rate_cycles": rates.get("cycles_per_wave_instr"),
             "launch_us_unprofiled": launch_us, "ns_simple": ns_simple, "ns_trans": ns_trans,
             "trans_per_wave": trans / d["SQ_WAVES"], "valu_per_wave": valu / d["SQ_WAVES"]}
 
@@ -95,23 +98,42 @@ def main():
             print(f"- {c}: {v:.4g}")
         d = cs
         avg_ns = sum(agg[k]) / len(agg[k])
-        if "SQ_ACTIVE_INST_VALU" in d and "SQ_BUSY_CYCLES" in d:
-            # SQ_* cycle counters are summed over SEs/XCDs; report ratios only
-            if d.get("SQ_WAVE_CYCLES"):
-                print(f"- derived: VALU issue share of wave cycles = {4*d['SQ_ACTIVE_INST_VALU']/d['SQ_WAVE_CYCLES']:.3f} "
-                      f"(ACTIVE_INST_VALU x4 / WAVE_CYCLES, both quad-cycle units)")
-            if d.get("SQ_INSTS_VALU") and d.get("SQ_WAVES"):
-                print(f"- derived: VALU instructions per wave = {d['SQ_INSTS_VALU']/d['SQ_WAVES']:.1f}")
-            if d.get("SQ_THREAD_CYCLES_VALU") and d.get("SQ_ACTIVE_INST_VALU"):
-                print(f"- derived: VALU lane utilisation = "
-                      f"{d['SQ_THREAD_CYCLES_VALU']/d['SQ_ACTIVE_INST_VALU']/64:.3f} "
-                      f"(THREAD_CYCLES_VALU / (ACTIVE_INST_VALU x 64))")
+        split = None
+        if d.get("SQ_WAVE_CYCLES"):
+            # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are all in quad-cycles and summed over waves:
+            # the three disjoint buckets of a wave's life (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+            wc = d["SQ_WAVE_CYCLES"]
+            split = {"issuing": d.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
+                     "issue_stalled": d.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                     "parked_on_waitcnt": d.get("SQ_WAIT_ANY", 0.0) / wc}
+            if d.get("SQ_ACTIVE_INST_VALU"):
+                split["issuing_valu"] = d["SQ_ACTIVE_INST_VALU"] / wc
+            print("- derived: share of a wave's cycles: issuing {issuing:.3f} (VALU {v:.3f}), issue-stalled "
+                  "{issue_stalled:.3f}, parked on s_waitcnt {parked_on_waitcnt:.3f} "
+                  "(ACTIVE_INST_ANY, ACTIVE_INST_VALU, WAIT_INST_ANY, WAIT_ANY over WAVE_CYCLES)".format(
+                      v=split.get("issuing_valu", float("nan")), **{k: split[k] for k in
+                                                                    ("issuing", "issue_stalled", "parked_on_waitcnt")}))
+        if d.get("SQ_INSTS_VALU") and d.get("SQ_WAVES"):
+            print(f"- derived: VALU instructions per wave = {d['SQ_INSTS_VALU']/d['SQ_WAVES']:.1f}")
+            clk = None
+            if d.get("GRBM_GUI_ACTIVE"):
+                clk = d["GRBM_GUI_ACTIVE"] / 8.0 / avg_ns  # GHz; reads high on dispatches under ~0.3 ms
+            print(f"- derived: VALU instructions per SIMD per launch = {d['SQ_INSTS_VALU']/1024:.0f}; over the "
+                  f"profiled launch time {avg_ns/1e3:.1f} us that is one per {avg_ns/(d['SQ_INSTS_VALU']/1024):.3f} ns "
+                  f"per SIMD (datasheet floor: 2 cycles = 0.833 ns at 2.4 GHz)"
+                  + (f"; GRBM_GUI_ACTIVE/8/time = {clk:.2f} GHz (unreliable under 0.3 ms)" if clk else ""))
+        if d.get("SQ_THREAD_CYCLES_VALU") and d.get("SQ_ACTIVE_INST_VALU"):
+            print(f"- derived: VALU lane utilisation = "
+                  f"{d['SQ_THREAD_CYCLES_VALU']/d['SQ_ACTIVE_INST_VALU']/64:.3f} "
+                  f"(THREAD_CYCLES_VALU / (ACTIVE_INST_VALU x 64))")
         vr = valu_roofline(root, d, avg_ns)
         if vr:
             print(f"- derived: VALU issue roofline = {vr['valu_roofline_frac']:.3f} of the un-profiled launch time "
                   f"({vr['valu_time_us']:.1f} us of VALU issue at the microbenchmark's 8-waves/SIMD rates -- "
                   f"{vr['ns_simple']:.3f} ns per simple, {vr['ns_trans']:.3f} ns per transcendental wave-instruction "
-                  f"per SIMD -- over {vr['launch_us_unprofiled']:.1f} us; {vr['trans_per_wave']:.0f} transcendentals "
+                  f"per SIMD"
+                  + (f", measured at {vr['valu_rate_mhz']:.0f} MHz in-kernel" if vr.get("valu_rate_mhz") else "")
+                  + f" -- over {vr['launch_us_unprofiled']:.1f} us; {vr['trans_per_wave']:.0f} transcendentals "
                   f"of {vr['valu_per_wave']:.0f} VALU instructions per wave)")
         if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
             fetch = 2.0 * d.get("FETCH_SIZE", 0.0) * 1024  # gfx950: reports half of wide coalesced reads
@@ -119,22 +141,23 @@ def main():
             if traffic_json and k.startswith("k_force<true"):
                 import json
                 valu = {}
-                if d.get("SQ_WAVE_CYCLES") and d.get("SQ_ACTIVE_INST_VALU"):
-                    valu["valu_issue_share"] = 4 * d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
+                if split:
+                    valu["wave_cycle_split"] = split
                 if d.get("SQ_INSTS_VALU") and d.get("SQ_WAVES"):
                     valu["valu_insts_per_wave"] = d["SQ_INSTS_VALU"] / d["SQ_WAVES"]
                 if d.get("SQ_THREAD_CYCLES_VALU") and d.get("SQ_ACTIVE_INST_VALU"):
                     valu["valu_lane_utilisation"] = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"] / 64
                 if vr:
                     valu.update({kk: vr[kk] for kk in ("valu_roofline_frac", "valu_time_us", "launch_us_unprofiled",
-                                                       "ns_simple", "ns_trans", "trans_per_wave")})
+                                                       "ns_simple", "ns_trans", "trans_per_wave", "valu_rate_mhz",
+                                                       "valu_rate_cycles")})
                 with open(traffic_json, "w") as fh:
                     json.dump({**valu, "kernel": k, "profile": os.path.basename(root), "fetch_bytes_per_launch": fetch,
                                "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                                "avg_launch_us_profiled": avg_ns / 1e3,
                                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
                                          "`python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline "
-                                         "--no-survey-literal`; FETCH_SIZE x2 (gfx950 wide-read correction) "
+                                         "--no-survey-literal --no-streamlined --no-large-arena --no-clock`; FETCH_SIZE x2 (gfx950 wide-read correction) "
                                          "x1024, WRITE_SIZE x1024 (MI355X_MICROARCH.md, HBM section)"}, fh)
             print(f"- derived: HBM-side traffic per launch = read {fetch/1e6:.1f} MB (FETCH_SIZE x2 x1024) + "
                   f"write {write/1e6:.1f} MB = {(fetch+write)/1e6:.1f} MB; at {avg_ns/1e3:.1f} us/launch = "
