@@ -61,12 +61,18 @@ constexpr int TILE = PB_TILE;
 #ifndef PB_FORCE_WAVES
 #define PB_FORCE_WAVES 1
 #endif
+#ifndef PB_NB2_WAVES
+#define PB_NB2_WAVES 8  // minimum waves per SIMD the two-neighbours-per-trip form is compiled for
+#endif
 #ifndef PB_THROUGHPUT_NB
 #define PB_THROUGHPUT_NB 1
 #endif
 // NB (template parameter of k_force): neighbours evaluated side by side per loop trip of the
-// one-lane-per-bot form.  1 is what ships (8 waves/SIMD, the VALU pipe is the limit); larger values
-// (more ILP per wave) measured no better at any size and are a build-time experiment only.
+// one-lane-per-bot form.  1 is what ships.  2 (two independent dependency chains per wave, the
+// software-pipelined two-wide loop in pbSweepC) is a build-time experiment: measured on MI355X at
+// 10^6 bots it is bit-identical and SLOWER at every register budget -- 124.9 us/step at 8 waves/SIMD
+// (64 VGPRs, 28 spilled), 120.8 at 7 (72), 119.8 at 6 (80), 121.4 at 5 (81, no bound) against 114.0
+// for NB = 1 (63 VGPRs, 8 waves/SIMD): waves, not ILP inside a wave, are what fills the VALU pipe.
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
@@ -332,6 +338,73 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
     }
     return;
   }
+  if (FLAT && NB == 2) {
+    // The same sweep with TWO neighbours per trip, evaluated side by side in the same basic blocks
+    // (pbPairEvalK<FAST, 2>: two independent dependency chains for the scheduler to interleave) and
+    // added in slot order.  The one-per-trip form above leaves ~a third of the SIMD's issue slots
+    // empty (a wave's pair evaluation is one long dependent chain and a launch's last waves run
+    // nearly alone); this form trades registers (<= 64, still 8 waves per SIMD) for ILP.  A range of
+    // odd length evaluates one slot past its end (spare elements; never accumulated).
+    const char *const prBytes = (const char *)&prIn[0];
+    const char *const velBytes = (const char *)&velIn[0];
+    const uint32_t selfOff = s * 16u;
+    auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
+    auto vat = [&](uint32_t off) __attribute__((always_inline)) { return *(const float2 *)(velBytes + (off >> 1)); };
+    auto two = [&](const float4 &qa, const float2 &va, const float4 &qb, const float2 &vb, uint32_t off,
+                   uint32_t end) __attribute__((always_inline)) {
+      const bool live[2] = {off != selfOff, (off + 16u != selfOff) && (off + 16u < end)};
+      const float bx[2] = {qa.x, qb.x}, by[2] = {qa.y, qb.y}, rb[2] = {qa.z, qb.z};
+      const float A[2] = {PAYLOAD ? attraction0 * qa.w * att1 : attraction0,
+                          PAYLOAD ? attraction0 * qb.w * att1 : attraction0};
+      const float K[2] = {PAYLOAD ? pbBandSlope(A[0]) : slope0, PAYLOAD ? pbBandSlope(A[1]) : slope0};
+      PbPairTerm t[2];
+      pbPairEvalK<FAST, 2>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K,
+                           [&](int k) { return k == 0 ? va : vb; }, t);
+      pbPairAdd(live[0], t[0], F);
+      pbPairAdd(live[1], t[1], F);
+    };
+    auto bounds = [&](int si, uint32_t &lo, uint32_t &hi) __attribute__((always_inline)) {
+      lo = hi = selfOff;
+      if (si < 10) {
+        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+        lo = (cellS[row + ((si & 1) ? 0u : mx0)] - base) * 16u;
+        hi = (cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base) * 16u;
+      }
+    };
+    const int stride = nseg == 1 ? 2 : 1;
+    uint32_t loA, hiA, loB, hiB;
+    bounds(0, loA, hiA);
+    bounds(stride, loB, hiB);
+    float4 qA = at(loA);
+    float2 vA = vat(loA);
+#pragma unroll 1
+    for (int si = 0; si < 10; si += stride) {
+      const uint32_t lo = loA, end = hiA;
+      float4 q0 = qA, q1 = at(lo + 16u);
+      float2 v0 = vA, v1 = vat(lo + 16u);
+      loA = loB;
+      hiA = hiB;
+      qA = at(loA);  // first posrad of the next segment
+      vA = vat(loA);
+      bounds(si + 2 * stride, loB, hiB);  // bounds of the one after
+      if (lo < end) {
+        uint32_t off = lo;
+        for (;;) {
+          const float4 n0 = at(off + 32u), n1 = at(off + 48u);
+          const float2 w0 = vat(off + 32u), w1 = vat(off + 48u);
+          two(q0, v0, q1, v1, off, end);
+          if ((off += 32u) >= end) break;
+          q0 = at(off + 32u);
+          q1 = at(off + 48u);
+          v0 = vat(off + 32u);
+          v1 = vat(off + 48u);
+          two(n0, w0, n1, w1, off, end);
+          if ((off += 32u) >= end) break;
+        }
+      }
+    }
+    return;
+  }
   // rolled on purpose: one copy of the pair loop in the binary (unrolling the five rows made ten)
 #pragma unroll 1
   for (int si = 0; si < 10; si++) {
@@ -409,7 +482,7 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
 // FASTOK: the simulation passed pbFastMathAllowed, so waves whose lanes all pass
 // pbLaneFastMathOk may use the exact fast sqrt/division forms.
 template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB>
-__global__ __launch_bounds__(TILE, PB_FORCE_WAVES) void k_force(const PbDevParams *__restrict__ params,
+__global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) void k_force(const PbDevParams *__restrict__ params,
                                                 const float4 *__restrict__ prIn, const float2 *__restrict__ velIn,
                                                 float4 *__restrict__ prOut, float2 *__restrict__ velOut,
                                                 const float *__restrict__ phase, const int *__restrict__ dead,

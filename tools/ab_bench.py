@@ -26,18 +26,24 @@ def main():
     ap.add_argument("--skip", type=int, default=100, help="untimed steps before the first round")
     ap.add_argument("--pitch", type=float, default=bench.LATTICE_PITCH)
     ap.add_argument("--lattice", default="square")
+    ap.add_argument("--libdir", default=None, help="load the libraries from this directory (experimental builds)")
     args = ap.parse_args()
+    if args.libdir:
+        from particlerobotsimulations_amd import _capi
+        _capi.LIB_DIR = os.path.abspath(args.libdir)
+        _capi.HIP_SO = os.path.join(_capi.LIB_DIR, "libparticlebot_hip.so")
+        _capi.HOST_SO = os.path.join(_capi.LIB_DIR, "libparticlebot_host.so")
     import particlerobotsimulations_amd as pb
     pb.legacy.cudaInit(0, None)
     n = args.bots
-    variants = [int(v) for v in args.variants.split(",")]
+    variants = args.variants.split(",")
     pos = (bench.square_lattice(n, args.pitch) if args.lattice == "square"
            else bench.hex_lattice(n, np.float32(args.pitch)))
     sims = {}
     for v in variants:
         sp, keep = bench.workload_params(n, seed=1)
         s = pb.Sim(sp, wall_half=240.0, keepalive=keep)
-        s.set_force_variant(v)
+        s.set_force_variant(int(v))
         s.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
                     phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
         s.step(args.skip)
@@ -55,7 +61,7 @@ def main():
         dev = np.abs(st["pos"].astype(np.float64) - ref["pos"]).max()
         t = np.array(times[v])
         print(f"variant {v}: us/step per round {np.round(t, 1).tolist()}  median {np.median(t):.1f}  min {t.min():.1f}  "
-              f"=> {n / np.median(t) * 1e6:.3e} particle-steps/s   bit-identical to variant {variants[0]}: {same}  max|dpos| {dev:.3g}")
+              f"=> {n / np.median(t) * 1e6:.3e} particle-steps/s   {sims[v].config()}   bit-identical to variant {variants[0]}: {same}  max|dpos| {dev:.3g}")
 
 
 if __name__ == "__main__":

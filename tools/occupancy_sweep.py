@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""us/step of the throughput form (one bot per lane, exact kernel) against the number of bots on the
+bench lattice: how a wave's lifetime and the launch's ramp/tail depend on waves per SIMD.
+  python tools/occupancy_sweep.py [--steps 300]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--sizes", default="16384,65536,131072,262144,393216,524288,655360,786432,1048576,1310720,"
+                                       "1572864,2097152,3145728,4194304")
+    args = ap.parse_args()
+    import particlerobotsimulations_amd as pb
+    pb.legacy.cudaInit(0, None)
+    for n in [int(x) for x in args.sizes.split(",")]:
+        sim = bench.make_sim(pb, n, bench.LATTICE_PITCH, seed=1)
+        sim.set_lanes_per_bot(1)
+        sim.step(100)
+        best = 1e9
+        for _ in range(3):
+            done, ms = sim.step_timed(args.steps)
+            best = min(best, ms * 1e3 / done)
+        sim.close()
+        waves = n / 64 / 1024
+        print(f"{n:9d} bots  {waves:6.2f} waves/SIMD  {best:8.2f} us/step  {best / waves:7.2f} us per wave-per-SIMD  "
+              f"{n / best * 1e6:.3e} particle-steps/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
