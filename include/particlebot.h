@@ -103,6 +103,11 @@ class Particlebot {
    * params.config says.  Unlike any hexagonal packing, four contacts per bot are numerically stable
    * under the reference's parameters: the O(N) placement for very large arenas. */
   void setSquareLattice(bool on) { squareLattice = on; }
+  /* Extension: phase-noise generator, PB_RNG_* of particlebot_hip.h (default PB_RNG_COUNTER; the
+   * `pb_rng` key of a .cfg: "pbrng", "curand" or "rocrand").  Re-initialises the per-bot generator
+   * states, as curand_setup does at construction (particlebot.cpp:165); call it before the first step. */
+  void setRng(int kind);
+  int rngKind() const { return rngKindV; }
   pbSim *engineHandle() { return sim; }
   /* host mirrors in original bot order (valid after reset(); refreshed by getArray/dump) */
   const float *hostPositions() const { return hPos; }
@@ -177,6 +182,7 @@ class Particlebot {
   bool exitOnMaxTime = true;
   float hexSpacing = 0.0f;
   bool squareLattice = false;
+  int rngKindV = 0; /* PB_RNG_COUNTER */
   PbLibcRand rng; /* seeded with params.seed at construction */
 };
 

@@ -30,12 +30,30 @@ extern "C" {
  * headless build a "GL buffer object" is a plain device buffer created with pbCreateBuffer(). */
 struct pbGraphicsResource;
 
+/* Phase-noise generators.  PB_RNG_COUNTER (default) is this project's own counter-based generator
+ * (seed, bot, draw) -> N(0,1), bit-identical between the HIP kernels and the CPU oracle.
+ * PB_RNG_XORWOW_CURAND restates cuRAND's published XORWOW algorithm (curand_init(seed, bot, 0) +
+ * curand_normal; particlebot_kernel_impl.cuh:36-51): integer stream cuRAND-compatible by construction,
+ * unverifiable in an image without CUDA.  PB_RNG_XORWOW_ROCRAND is the same generator with rocRAND's
+ * seeding constants, bit-identical to rocrand_device::xorwow_engine (csrc/pb_xorwow.hpp). */
+enum { PB_RNG_COUNTER = 0, PB_RNG_XORWOW_CURAND = 1, PB_RNG_XORWOW_ROCRAND = 2 };
+
 /* Per-bot RNG state crossing the boundary where the reference passes `curandState*`
- * (particlebot.cuh:73-78, particlebot.h:98).  Counter-based: (seed, bot, draw). */
+ * (particlebot.cuh:73-78, particlebot.h:98): 48 bytes, the size of cuRAND's curandStateXORWOW, so a
+ * caller that allocates sizeof(curandState) * nCells gets the same bytes. */
 typedef struct pbRngState {
-  unsigned seed;
-  unsigned draw;
+  unsigned d;           /* XORWOW: Weyl sequence value          | counter generator: the seed */
+  unsigned v[5];        /* XORWOW: the five xorshift words      | counter generator: v[0] = draws so far */
+  int boxmuller_flag;   /* XORWOW: nonzero while boxmuller_extra holds the second normal of a pair */
+  int kind;             /* PB_RNG_* */
+  float boxmuller_extra;
+  float reserved[3];
 } pbRngState;
+
+/* Generator that the legacy boundary's curand_setup() initialises (process-wide, like the reference's
+ * one global parameter block); PB_RNG_COUNTER until changed.  Returns 0, or nonzero for a bad kind. */
+int pbSetRngKind(int kind);
+int pbGetRngKind(void);
 
 /* ------------------------------------------------------------------------------------------ */
 /* (1) reference device boundary                                                               */
@@ -227,6 +245,15 @@ int pbSimSetResident(pbSim *sim, int mode);
  * constants are outside the fast forms' domain), the effective lanes per bot of the per-step kernel,
  * whether the resident multi-step kernel is used, and the phase-noise generator.  bench.py echoes it
  * into its JSON line so a reader can see which kernel a number belongs to. */
+/* Phase-noise generator of a batch (PB_RNG_*; default PB_RNG_COUNTER).  Selecting an XORWOW kind builds
+ * one 48-byte state per bot -- curand_init(member's seed, bot, 0): the 2^67-step subsequence skip is a
+ * 160x160 GF(2) jump per set bit of the bot index -- and restarts the draw counter.
+ * pbSimSetPhaseDraws(k) afterwards replays k draws (exact checkpoint resume). */
+int pbSimSetRng(pbSim *sim, int kind);
+/* The generator states of one member in ORIGINAL bot order (n x pbRngState); PB_ERR_ARG with the
+ * counter generator, which has none. */
+int pbSimGetRngStatesOf(pbSim *sim, unsigned member, pbRngState *states);
+
 typedef struct pbSimConfig {
   int force_variant;
   int force_kind;

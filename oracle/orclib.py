@@ -46,6 +46,7 @@ class OrcParams(C.Structure):
         ("display_interval", C.c_int32), ("video_interval", C.c_int32),
         ("csv_filename", C.c_char * 300), ("video_filename", C.c_char * 300),
         ("wallHalf", C.c_float),
+        ("rngKind", C.c_int32),
     ]
 
     def to_dict(self):
@@ -124,6 +125,9 @@ def lib():
     L.orc_normal.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     L.orc_normal.restype = C.c_float
     L.orc_add_normal_noise.argtypes = [C.c_uint32, C.c_uint32, _f32p, C.c_float, C.c_uint32]
+    L.orc_xorwow_outputs.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, _u32p]
+    L.orc_xorwow_normals.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
+    L.orc_xorwow_jump_rows.argtypes = [_u32p]
     L.orc_sim_create.argtypes = [_PP]
     L.orc_sim_create.restype = C.c_void_p
     L.orc_sim_destroy.argtypes = [C.c_void_p]

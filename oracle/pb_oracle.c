@@ -193,6 +193,11 @@ void orc_set_param(OrcParams *p, const char *name, const char *value) {
     }
     return;
   }
+  /* extension key of the product's loader (csrc/pb_config.cpp), tried after every reference key */
+  if (strncmp(name, "pb_rng", 6) == 0) {
+    p->rngKind = strncmp(value, "curand", 6) == 0 ? 1 : strncmp(value, "rocrand", 7) == 0 ? 2 : 0;
+    return;
+  }
   /* unknown keys silently consume their value line */
 }
 
@@ -782,6 +787,211 @@ void orc_add_normal_noise(uint32_t seed, uint32_t draw, float *val, float std, u
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* phase noise, generator 2: cuRAND-compatible XORWOW (particlebot_kernel_impl.cuh:36-51:       */
+/* curand_init(seed, i, 0) per bot, curand_normal per phase update).  cuRAND is a third-party    */
+/* dependency absent from the reference tree and from this image; this restates its PUBLISHED    */
+/* algorithm (curand_kernel.h: curandStateXORWOW, _curand_init_scratch, curand(), curand_normal) */
+/* independently of the product's csrc/pb_xorwow.hpp: the 2^67-step subsequence jump is built    */
+/* here as a matrix of OUTPUT-bit masks and applied by AND + parity, bots are initialised         */
+/* SEQUENTIALLY (state of bot i+1 = one jump of bot i), where the product uses input-bit images  */
+/* and a binary decomposition of the bot index.  kind 1: cuRAND's seeding constants; kind 2:      */
+/* rocRAND's (rocrand_xorwow.h:113-116), which rocRAND's own host engine pins (tests/test_xorwow).*/
+/* The uniform -> normal transform uses fixed-order fp32 polynomials (log, sin, cos) so that CPU   */
+/* and GPU agree bit for bit; against CUDA's logf/__sincosf it agrees to float rounding only.     */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct OrcXw {
+  uint32_t v[5];
+  uint32_t d;
+  int32_t have;
+  float extra;
+} OrcXw;
+
+static void xw_shift(uint32_t *v) {
+  uint32_t t = v[0] ^ (v[0] >> 2);
+  v[0] = v[1];
+  v[1] = v[2];
+  v[2] = v[3];
+  v[3] = v[4];
+  v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+}
+
+static uint32_t xw_next(OrcXw *s) {
+  xw_shift(s->v);
+  s->d += 362437u;
+  return s->v[4] + s->d;
+}
+
+static void xw_seed(OrcXw *s, uint64_t seed, int kind) {
+  const uint32_t x0 = kind == 2 ? 0x2c7f967fu : 0xaad26b49u, x1 = kind == 2 ? 0xa03697cbu : 0xf7dcefddu;
+  const uint32_t m0 = kind == 2 ? 1228688033u : 1099087573u, m1 = kind == 2 ? 2073658381u : 2591861531u;
+  const uint32_t s0 = (uint32_t)seed ^ x0, s1 = (uint32_t)(seed >> 32) ^ x1;
+  const uint32_t t0 = m0 * s0, t1 = m1 * s1;
+  s->d = 6615241u + t1 + t0;
+  s->v[0] = 123456789u + t0;
+  s->v[1] = 362436069u ^ t0;
+  s->v[2] = 521288629u + t1;
+  s->v[3] = 88675123u ^ t1;
+  s->v[4] = 5783321u + t0;
+  s->have = 0;
+  s->extra = 0.0f;
+}
+
+/* J[o] = 160-bit mask (5 words) of the INPUT bits whose parity is output bit o after 2^67 steps */
+static uint32_t g_xwJump[160][5];
+static int g_xwJumpReady = 0;
+
+static void xw_build_jump(void) {
+  if (g_xwJumpReady) return;
+  static uint32_t A[160][5], B[160][5];
+  memset(A, 0, sizeof A);
+  for (int i = 0; i < 160; i++) { /* one step applied to e_i tells which outputs depend on input i */
+    uint32_t v[5] = {0, 0, 0, 0, 0};
+    v[i >> 5] = 1u << (i & 31);
+    xw_shift(v);
+    for (int o = 0; o < 160; o++)
+      if ((v[o >> 5] >> (o & 31)) & 1u) A[o][i >> 5] |= 1u << (i & 31);
+  }
+  for (int sq = 0; sq < 67; sq++) { /* (A o A)[o] = XOR of A[i] over the inputs i of A[o] */
+    for (int o = 0; o < 160; o++) {
+      uint32_t r[5] = {0, 0, 0, 0, 0};
+      for (int i = 0; i < 160; i++)
+        if ((A[o][i >> 5] >> (i & 31)) & 1u)
+          for (int w = 0; w < 5; w++) r[w] ^= A[i][w];
+      memcpy(B[o], r, sizeof r);
+    }
+    memcpy(A, B, sizeof A);
+  }
+  memcpy(g_xwJump, A, sizeof A);
+  g_xwJumpReady = 1;
+}
+
+static void xw_jump(uint32_t *v) { /* v <- state 2^67 steps later */
+  uint32_t r[5] = {0, 0, 0, 0, 0};
+  for (int o = 0; o < 160; o++) {
+    uint32_t acc = 0;
+    for (int w = 0; w < 5; w++) acc ^= g_xwJump[o][w] & v[w];
+    r[o >> 5] |= (uint32_t)(__builtin_popcount(acc) & 1) << (o & 31);
+  }
+  memcpy(v, r, sizeof r);
+}
+
+static float xw_log(float u) {
+  uint32_t bits;
+  memcpy(&bits, &u, 4);
+  int e = (int)(bits >> 23) - 127;
+  uint32_t mb = (bits & 0x007FFFFFu) | 0x3F800000u;
+  float m;
+  memcpy(&m, &mb, 4);
+  if (m > 1.41421356f) {
+    m = m * 0.5f;
+    e += 1;
+  }
+  const float t = (m - 1.0f) / (m + 1.0f);
+  const float t2 = t * t;
+  float p = 0.111111111f;
+  p = p * t2 + 0.142857143f;
+  p = p * t2 + 0.2f;
+  p = p * t2 + 0.333333333f;
+  p = p * t2 + 1.0f;
+  return 2.0f * t * p + (float)e * 0.693147181f;
+}
+
+static void xw_sincos(float v, float *sn, float *cs) {
+  int q = (int)(v * 0.636619772f);
+  float a = v - (float)q * 1.57079633f;
+  if (a < 0.0f) {
+    q -= 1;
+    a = a + 1.57079633f;
+  }
+  const float a2 = a * a;
+  float s = -2.50521084e-8f;
+  s = s * a2 + 2.75573192e-6f;
+  s = s * a2 - 1.98412698e-4f;
+  s = s * a2 + 8.33333333e-3f;
+  s = s * a2 - 1.66666667e-1f;
+  s = s * a2 + 1.0f;
+  s = s * a;
+  float c = 2.08767570e-9f;
+  c = c * a2 - 2.75573192e-7f;
+  c = c * a2 + 2.48015873e-5f;
+  c = c * a2 - 1.38888889e-3f;
+  c = c * a2 + 4.16666667e-2f;
+  c = c * a2 - 0.5f;
+  c = c * a2 + 1.0f;
+  switch (q & 3) {
+    case 0: *sn = s, *cs = c; break;
+    case 1: *sn = c, *cs = -s; break;
+    case 2: *sn = -s, *cs = -c; break;
+    default: *sn = -c, *cs = s; break;
+  }
+}
+
+/* curand_normal(curandStateXORWOW_t*): Box-Muller on two consecutive outputs, second value kept */
+static float xw_normal(OrcXw *s, int kind) {
+  if (s->have) {
+    s->have = 0;
+    return s->extra;
+  }
+  const uint32_t x = xw_next(s);
+  const uint32_t y = xw_next(s);
+  float u, v;
+  if (kind == 2) { /* rocrand_normal.h:56-57 */
+    u = 2.3283064e-10f + ((float)x * 2.3283064e-10f);
+    v = 1.46291807e-09f + ((float)y * 1.46291807e-09f);
+  } else { /* CURAND_2POW32_INV, CURAND_2POW32_INV_2PI and their halves */
+    const float c = 2.3283064e-10f, c2pi = 2.3283064e-10f * 6.2831855f;
+    u = (float)x * c + (c / 2.0f);
+    v = (float)y * c2pi + (c2pi / 2.0f);
+  }
+  const float r = sqrtf(-2.0f * xw_log(u));
+  float sn, cs;
+  xw_sincos(v, &sn, &cs);
+  s->extra = cs * r;
+  s->have = 1;
+  return sn * r;
+}
+
+/* curand_setup_kernel (impl.cuh:36-41): st[i] = curand_init(seed, i, 0), i = 0..n-1 */
+static void xw_setup(OrcXw *st, uint32_t seed, uint32_t n, int kind) {
+  xw_build_jump();
+  if (!n) return;
+  xw_seed(&st[0], (uint64_t)seed, kind);
+  for (uint32_t i = 1; i < n; i++) {
+    st[i] = st[i - 1];
+    xw_jump(st[i].v); /* d is unchanged: 362437 * 2^67 = 0 mod 2^32 */
+  }
+}
+
+/* test hooks: the first `count` raw outputs of curand_init(seed, subsequence, 0), and the states */
+void orc_xorwow_outputs(int kind, uint64_t seed, uint32_t subsequence, uint32_t count, uint32_t *out) {
+  OrcXw s;
+  xw_build_jump();
+  xw_seed(&s, seed, kind);
+  for (uint32_t i = 0; i < subsequence; i++) xw_jump(s.v);
+  for (uint32_t i = 0; i < count; i++) out[i] = xw_next(&s);
+}
+
+void orc_xorwow_normals(int kind, uint32_t seed, uint32_t nbots, uint32_t draws, float *out /* draws x nbots */) {
+  OrcXw *st = (OrcXw *)malloc(sizeof(OrcXw) * (nbots ? nbots : 1));
+  xw_setup(st, seed, nbots, kind);
+  for (uint32_t k = 0; k < draws; k++)
+    for (uint32_t i = 0; i < nbots; i++) out[(size_t)k * nbots + i] = xw_normal(&st[i], kind);
+  free(st);
+}
+
+/* the 2^67-step jump as the product stores it (row r = image of input bit r), for cross-checks */
+void orc_xorwow_jump_rows(uint32_t *rows /* 160 x 5 */) {
+  xw_build_jump();
+  for (int r = 0; r < 160; r++) {
+    uint32_t v[5] = {0, 0, 0, 0, 0};
+    v[r >> 5] = 1u << (r & 31);
+    xw_jump(v);
+    memcpy(rows + (size_t)r * 5, v, sizeof v);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* simulation object                                                                            */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -795,6 +1005,7 @@ struct OrcSim {
   int32_t *dead;
   uint32_t *hash, *index, *cellStart, *cellEnd;
   float *sPos, *sVel, *sRad;
+  OrcXw *xw; /* per-bot XORWOW states when P.rngKind != 0 (the reference's dState) */
 };
 
 static void *zalloc(size_t bytes) {
@@ -828,6 +1039,10 @@ OrcSim *orc_sim_create(const OrcParams *P) {
   s->sPos = (float *)zalloc(8 * n);
   s->sVel = (float *)zalloc(8 * n);
   s->sRad = (float *)zalloc(4 * n);
+  if (P->rngKind != 0) { /* particlebot.cpp:161-165 curand_setup(dState, nCells) */
+    s->xw = (OrcXw *)zalloc(sizeof(OrcXw) * (n ? n : 1));
+    xw_setup(s->xw, P->seed, s->n, P->rngKind);
+  }
   return s;
 }
 
@@ -847,6 +1062,7 @@ void orc_sim_destroy(OrcSim *s) {
   free(s->sPos);
   free(s->sVel);
   free(s->sRad);
+  free(s->xw);
   free(s);
 }
 
@@ -1062,7 +1278,14 @@ int orc_sim_update(OrcSim *s, float dt, float sort_interval) {
       float spacing = 2.0f * P->min_radius;
       orc_updatePhase(P, s->pos, s->phase, spacing, max_d, min_d, n);
       if (P->phase_std) {
-        orc_add_normal_noise(P->seed, s->phaseDraws, s->phase, P->phase_std, n);
+        if (s->xw) { /* impl.cuh:43-51 with the XORWOW generator */
+          for (uint32_t i = 0; i < n; i++) {
+            float noise = P->phase_std * xw_normal(&s->xw[i], P->rngKind);
+            s->phase[i] += noise;
+          }
+        } else {
+          orc_add_normal_noise(P->seed, s->phaseDraws, s->phase, P->phase_std, n);
+        }
         s->phaseDraws++;
       }
     }
@@ -1170,6 +1393,7 @@ void *orc_sim_array(OrcSim *s, int which) {
     case 6: return s->dead;
     case 7: return s->hash;
     case 8: return s->index;
+    case 9: return s->xw;
     default: return NULL;
   }
 }

@@ -69,6 +69,9 @@ typedef struct OrcParams {
   /* extension: wall half-extent of the integrator clamp (reference hard-codes 64,
    * particlebot_kernel_impl.cuh:75-97) */
   float wallHalf;
+  /* extension: phase-noise generator.  0 = PB-RNG v1 (counter based), 1 = cuRAND-compatible XORWOW
+   * (particlebot_kernel_impl.cuh:36-51), 2 = the same generator with rocRAND's seeding constants */
+  int32_t rngKind;
 } OrcParams;
 
 /* main.cpp:832-911 defaults (seed is NOT time(NULL) here: it is set to 0 and must come from the
@@ -142,6 +145,13 @@ void *orc_sim_array(OrcSim *s, int which);
 /* number of worker threads used by the OpenMP loops (1 when built without OpenMP) */
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
+
+/* XORWOW test hooks (the generator-2 section of pb_oracle.c): raw outputs of
+ * curand_init(seed, subsequence, 0); normals of bots 0..nbots-1 over `draws` phase updates
+ * (out[draw][bot]); the 2^67-step jump matrix in the product's row layout (160 x 5 words). */
+void orc_xorwow_outputs(int kind, uint64_t seed, uint32_t subsequence, uint32_t count, uint32_t *out);
+void orc_xorwow_normals(int kind, uint32_t seed, uint32_t nbots, uint32_t draws, float *out);
+void orc_xorwow_jump_rows(uint32_t *rows);
 
 #ifdef __cplusplus
 }

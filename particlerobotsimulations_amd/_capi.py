@@ -56,7 +56,12 @@ class SimParams(C.Structure):
 
 
 class pbRngState(C.Structure):
-    _fields_ = [("seed", C.c_uint), ("draw", C.c_uint)]
+    """48 bytes = sizeof(curandStateXORWOW) (include/particlebot_hip.h)."""
+    _fields_ = [("d", C.c_uint), ("v", C.c_uint * 5), ("boxmuller_flag", C.c_int), ("kind", C.c_int),
+                ("boxmuller_extra", C.c_float), ("reserved", C.c_float * 3)]
+
+
+PB_RNG_COUNTER, PB_RNG_XORWOW_CURAND, PB_RNG_XORWOW_ROCRAND = 0, 1, 2
 
 
 class pbSimStats(C.Structure):
@@ -132,6 +137,10 @@ SYMBOLS = {
     "pbSimSetLanesPerBot": (_I, [_VP, _I]),
     "pbSimSetResident": (_I, [_VP, _I]),
     "pbSimGetConfig": (_I, [_VP, C.POINTER(pbSimConfig)]),
+    "pbSimSetRng": (_I, [_VP, _I]),
+    "pbSimGetRngStatesOf": (_I, [_VP, _U, _VP]),
+    "pbSetRngKind": (_I, [_I]),
+    "pbGetRngKind": (_I, []),
     "pbClockSampleBegin": (_I, [C.POINTER(_VP), C.c_double]),
     "pbClockSampleEnd": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pbSelfTest": (_I, [C.c_ulonglong] + [C.POINTER(C.c_ulonglong)] * 4),

@@ -205,6 +205,17 @@ void Particlebot::_initialize() {
   curand_setup(dState, (int)n);
 }
 
+void Particlebot::setRng(int kind) {
+  if (kind != PB_RNG_COUNTER && kind != PB_RNG_XORWOW_CURAND && kind != PB_RNG_XORWOW_ROCRAND) die("setRng: bad kind");
+  rngKindV = kind;
+  if (engineKind == Engine::Fused) {
+    if (pbSimSetRng(sim, kind) != PB_OK) die("pbSimSetRng");
+  } else if (engineKind == Engine::Legacy) {
+    pbSetRngKind(kind);
+    curand_setup(dState, (int)params.nCells);
+  }
+}
+
 void Particlebot::_finalize() {
   if (sim) {
     pbSimDestroy(sim);

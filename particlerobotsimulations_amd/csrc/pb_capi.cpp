@@ -9,12 +9,14 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "particlebot.h"
 #include "pb_config.hpp"
+#include "pb_xorwow.hpp"
 
 extern "C" {
 
@@ -47,6 +49,7 @@ struct pbFlatConfig {
   char csv_filename[300];
   char video_filename[300];
   float wallHalf;
+  int rngKind;  // pb_rng (PB_RNG_*)
 };
 
 }  // extern "C"
@@ -140,6 +143,7 @@ void flatten(const PbRunConfig &cfg, pbFlatConfig *o) {
   snprintf(o->csv_filename, sizeof(o->csv_filename), "%s", cfg.csv_filename.c_str());
   snprintf(o->video_filename, sizeof(o->video_filename), "%s", cfg.video_filename.c_str());
   o->wallHalf = cfg.wallHalf();
+  o->rngKind = cfg.rng_kind;
 }
 
 struct HostSim {
@@ -183,6 +187,7 @@ void *pbHostCreate(const char *cfg_path, const char *overrides, int engine) {
   h->bot->setExitOnMaxTime(false);
   h->bot->setHexSpacing(h->cfg.hex_spacing);
   h->bot->setSquareLattice(h->cfg.square_lattice);
+  h->bot->setRng(h->cfg.rng_kind);
   return h;
 }
 
@@ -341,6 +346,7 @@ void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const
       Particlebot *bot = new Particlebot(cfg->params, Particlebot::Engine::HostOnly, cfg->wallHalf());
       bot->setHexSpacing(cfg->hex_spacing);
       bot->setSquareLattice(cfg->square_lattice);
+      bot->setRng(cfg->rng_kind);
       bot->reset();
       e->bots[k] = bot;
     }
@@ -361,6 +367,11 @@ void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const
   std::vector<SimParams> params;
   for (int k = 0; k < nmembers; k++) params.push_back(e->bots[k]->getParams());
   if (pbSimCreateBatch(&e->sim, params.data(), nmembers, e->cfgs[0]->wallHalf()) != PB_OK) {
+    fprintf(stderr, "pbEnsembleCreate: %s\n", pbGetLastErrorString());
+    delete e;
+    return nullptr;
+  }
+  if (e->cfgs[0]->rng_kind != 0 && pbSimSetRng(e->sim, e->cfgs[0]->rng_kind) != PB_OK) {
     fprintf(stderr, "pbEnsembleCreate: %s\n", pbGetLastErrorString());
     delete e;
     return nullptr;
@@ -462,6 +473,40 @@ int pbEnsembleGetState(void *ev, int member, float *pos, float *vel, float *rad)
 }
 
 unsigned pbEnsembleNumBots(void *ev) { return ((Ensemble *)ev)->bots[0]->getParams().nCells; }
+
+// ---- csrc/pb_xorwow.hpp on the host (CPU tests: the same code the kernels run) -------------------
+static const uint32_t *hostJumpTable() {
+  static std::vector<uint32_t> table;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    table.resize(PB_XW_TABLE_WORDS);
+    pbXorwowBuildJumpTable(table.data());
+  });
+  return table.data();
+}
+
+// the first `count` raw outputs of curand_init(seed, subsequence, 0)
+void pbHostXorwowOutputs(int kind, unsigned long long seed, unsigned subsequence, unsigned count, unsigned *out) {
+  pbRngState s;
+  pbXorwowSeed(s, seed, kind);
+  pbXorwowSkipSubsequences(s, subsequence, hostJumpTable());
+  for (unsigned i = 0; i < count; i++) out[i] = pbXorwowNext(s);
+}
+
+// `draws` normals of each of the bots 0..nbots-1 (out[draw][bot]), as add_normal_noise consumes them
+void pbHostXorwowNormals(int kind, unsigned seed, unsigned nbots, unsigned draws, float *out) {
+  for (unsigned i = 0; i < nbots; i++) {
+    pbRngState s;
+    pbXorwowSeed(s, (uint64_t)seed, kind);
+    pbXorwowSkipSubsequences(s, i, hostJumpTable());
+    for (unsigned k = 0; k < draws; k++) out[(size_t)k * nbots + i] = pbXorwowNormal(s);
+  }
+}
+
+// table[k] (160 x 5 words), k = 0..31
+void pbHostXorwowJumpMatrix(unsigned k, unsigned *rows) {
+  memcpy(rows, hostJumpTable() + (size_t)(k & 31u) * PB_XW_MAT_WORDS, sizeof(uint32_t) * PB_XW_MAT_WORDS);
+}
 
 unsigned pbHostNumBots(void *hv) { return ((HostSim *)hv)->bot->getParams().nCells; }
 

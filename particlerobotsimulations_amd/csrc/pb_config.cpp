@@ -68,6 +68,7 @@ PbRunConfig::PbRunConfig() {
   arena_half = 0.0f;
   hex_spacing = 0.0f;
   square_lattice = false;
+  rng_kind = 0;
   repoint();
 }
 
@@ -186,6 +187,12 @@ void PbRunConfig::setParam(const std::string &name, const std::string &value) {
     else if (value.rfind("blob", 0) == 0) params.config = CONFIG_BLOB;
     else if (value.rfind("lighttest7", 0) == 0) params.config = CONFIG_LIGHTTEST_7;
     else params.config = CONFIG_RANDOM;
+  }
+  else if (is("pb_rng", 6)) {
+    // phase-noise generator (include/particlebot_hip.h PB_RNG_*): "curand" = cuRAND-compatible XORWOW
+    // (what the reference's curand_init/curand_normal draw), "rocrand" = the same generator with
+    // rocRAND's seeding constants, anything else = this project's counter generator
+    rng_kind = value.rfind("curand", 0) == 0 ? 1 : value.rfind("rocrand", 0) == 0 ? 2 : 0;
   }
   // anything else: the value line is consumed and ignored, as in the reference
 }

@@ -39,6 +39,7 @@
 #include "particlebot_hip.h"
 #include "pb_device.hpp"
 #include "pb_internal.hpp"
+#include "pb_xorwow.hpp"
 
 namespace {
 
@@ -854,10 +855,12 @@ __global__ __launch_bounds__(TILE) void k_min_dist2(const PbDevParams *__restric
   }
 }
 
-// updatePhase (impl.cuh:264-290) + add_normal_noise (impl.cuh:43-51) in slot order
+// updatePhase (impl.cuh:264-290) + add_normal_noise (impl.cuh:43-51) in slot order.  rng: per-bot
+// XORWOW states in ORIGINAL order (nullptr: the counter generator, which needs none).
 __global__ __launch_bounds__(TILE) void k_phase(const PbDevParams *__restrict__ params, const float4 *__restrict__ pr,
                                                 const uint32_t *__restrict__ orig, float *__restrict__ phase,
-                                                uint32_t n, const float *__restrict__ minD, uint32_t draw) {
+                                                uint32_t n, const float *__restrict__ minD, uint32_t draw,
+                                                pbRngState *__restrict__ rng) {
   const PbDevParams &P = params[blockIdx.y];
   const uint32_t l = blockIdx.x * TILE + threadIdx.x;
   if (l >= n) return;
@@ -866,10 +869,34 @@ __global__ __launch_bounds__(TILE) void k_phase(const PbDevParams *__restrict__ 
   const float spacing = 2.0f * P.min_radius;  // particlebot.cpp:229
   float ph = pbPhase(P, q.x, q.y, spacing, minD[blockIdx.y], phase[s]);
   if (P.phase_std != 0.0f) {
-    const float noise = P.phase_std * pbNormal(P.seed, orig[s], draw);
+    float z;
+    if (rng) {
+      pbRngState st = rng[blockIdx.y * n + orig[s]];
+      z = pbXorwowNormal(st);
+      rng[blockIdx.y * n + orig[s]] = st;
+    } else {
+      z = pbNormal(P.seed, orig[s], draw);
+    }
+    const float noise = P.phase_std * z;
     ph += noise;
   }
   phase[s] = ph;
+}
+
+// curand_setup_kernel (impl.cuh:36-41): state[i] = curand_init(seed of the simulation, i, 0), then
+// `draws` normals already consumed (checkpoint resume)
+__global__ __launch_bounds__(TILE) void k_rng_init(const PbDevParams *__restrict__ params,
+                                                   pbRngState *__restrict__ rng, uint32_t n, int kind,
+                                                   const uint32_t *__restrict__ jump, uint32_t draws) {
+  const PbDevParams &P = params[blockIdx.y];
+  const uint32_t i = blockIdx.x * TILE + threadIdx.x;
+  if (i >= n) return;
+  pbRngState st;
+  pbXorwowSeed(st, (uint64_t)P.seed, kind);
+  pbXorwowSkipSubsequences(st, i, jump);
+  if (P.phase_std != 0.0f)
+    for (uint32_t k = 0; k < draws; k++) (void)pbXorwowNormal(st);
+  rng[blockIdx.y * n + i] = st;
 }
 
 // host arrays of ONE simulation (original order, staged on the device) -> slot order.  The staged
@@ -1100,6 +1127,7 @@ struct pbSim {
   uint32_t *sortedKeys = nullptr;  // keys[0] or keys[1]: composite keys of the slots, as of the last sort
   std::vector<uint32_t> layoutOrig, layoutKeys;  // host staging of pbSimSetLayoutOf
   std::vector<char> layoutGiven;
+  pbRngState *rngState = nullptr;  // total, ORIGINAL order; only with an XORWOW generator (rng != 0)
   uint32_t *dMin = nullptr;  // nsims
   float *dMinD = nullptr;    // nsims
   uint32_t *hMin = nullptr;  // pinned, nsims
@@ -1308,7 +1336,7 @@ int phaseUpdate(pbSim *S) {
   }
   PB_TRY(hipMemcpyAsync(S->dMinD, S->hMinD, sizeof(float) * S->nsims, hipMemcpyHostToDevice, S->stream));
   hipLaunchKernelGGL(k_phase, g, b, 0, S->stream, S->dP, S->pr[c], S->orig[c], S->phase[c], n, S->dMinD,
-                     S->phaseDraws);
+                     S->phaseDraws, S->rng != PB_RNG_COUNTER ? S->rngState : (pbRngState *)nullptr);
   PB_TRY(hipGetLastError());
   // the draw counter advances when any simulation draws; simulations with phase_std == 0 skip it
   bool anyNoise = false;
@@ -1428,6 +1456,7 @@ void pbSimDestroy(pbSim *S) {
   (void)hipFree(S->cellS);
   (void)hipFree(S->hist);
   (void)hipFree(S->slotOf);
+  (void)hipFree(S->rngState);
   (void)hipFree(S->dMin);
   (void)hipFree(S->dMinD);
   (void)hipFree(S->stage);
@@ -1729,9 +1758,42 @@ int pbSimGetPhaseDraws(pbSim *S, unsigned *draws) {
   return PB_OK;
 }
 
+namespace {
+// (re)build every bot's XORWOW state: curand_init(seed, bot, 0) advanced by `draws` normals
+int rngInit(pbSim *S, unsigned draws) {
+  hipError_t e = hipSuccess;
+  const uint32_t *jump = pbXorwowDeviceTable(&e);
+  if (!jump) PB_TRY(e);
+  if (!S->rngState) PB_TRY(hipMalloc((void **)&S->rngState, sizeof(pbRngState) * (size_t)S->total));
+  hipLaunchKernelGGL(k_rng_init, gridOf(S), dim3(TILE), 0, S->stream, S->dP, S->rngState, S->n, S->rng, jump, draws);
+  PB_TRY(hipGetLastError());
+  PB_TRY(hipStreamSynchronize(S->stream));
+  return PB_OK;
+}
+}  // namespace
+
 int pbSimSetPhaseDraws(pbSim *S, unsigned draws) {
   if (!S) return PB_ERR_ARG;
   S->phaseDraws = draws;
+  if (S->rng != PB_RNG_COUNTER) return rngInit(S, draws);  // the states are a function of (seed, bot, draws)
+  return PB_OK;
+}
+
+int pbSimSetRng(pbSim *S, int kind) {
+  if (!S || (kind != PB_RNG_COUNTER && kind != PB_RNG_XORWOW_CURAND && kind != PB_RNG_XORWOW_ROCRAND)) {
+    g_lastError = "pbSimSetRng: kind must be PB_RNG_COUNTER, PB_RNG_XORWOW_CURAND or PB_RNG_XORWOW_ROCRAND";
+    return PB_ERR_ARG;
+  }
+  S->rng = kind;
+  S->phaseDraws = 0;
+  if (kind == PB_RNG_COUNTER) return PB_OK;
+  return rngInit(S, 0);
+}
+
+int pbSimGetRngStatesOf(pbSim *S, unsigned sim, pbRngState *states) {
+  if (!S || sim >= S->nsims || !states || S->rng == PB_RNG_COUNTER || !S->rngState) return PB_ERR_ARG;
+  PB_TRY(hipStreamSynchronize(S->stream));
+  PB_TRY(hipMemcpy(states, S->rngState + (size_t)sim * S->n, sizeof(pbRngState) * (size_t)S->n, hipMemcpyDeviceToHost));
   return PB_OK;
 }
 

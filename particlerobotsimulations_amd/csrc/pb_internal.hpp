@@ -31,3 +31,7 @@ static inline int pbKeyBits(uint32_t numKeys) {
   while (b < 32 && (numKeys > (1u << b))) b++;
   return b < 1 ? 1 : b;
 }
+
+// ---- XORWOW jump table (pb_xorwow.hpp) on the current device: built on the host once per process,
+// uploaded once; returns nullptr and sets *err after a HIP error (pb_legacy.hip)
+const uint32_t *pbXorwowDeviceTable(hipError_t *err);

@@ -13,12 +13,34 @@
 #include "particlebot_hip.h"
 #include "pb_device.hpp"
 #include "pb_internal.hpp"
+#include "pb_xorwow.hpp"
+
+const uint32_t *pbXorwowDeviceTable(hipError_t *err) {
+  static std::mutex mu;
+  static uint32_t *dev = nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (err) *err = hipSuccess;
+  if (dev) return dev;
+  std::vector<uint32_t> table(PB_XW_TABLE_WORDS);
+  pbXorwowBuildJumpTable(table.data());
+  uint32_t *d = nullptr;
+  hipError_t e = hipMalloc((void **)&d, sizeof(uint32_t) * PB_XW_TABLE_WORDS);
+  if (e == hipSuccess) e = hipMemcpy(d, table.data(), sizeof(uint32_t) * PB_XW_TABLE_WORDS, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (err) *err = e;
+    if (d) (void)hipFree(d);
+    return nullptr;
+  }
+  dev = d;
+  return dev;
+}
 
 namespace {
 
 PbDevParams g_P;  // the reference's single `__constant__ SimParams params` (impl.cuh:27)
 SimParams g_hostParams;
 bool g_haveParams = false;
+int g_rngKind = PB_RNG_COUNTER;  // generator curand_setup() initialises (pbSetRngKind)
 float g_wallHalf = 64.0f;
 
 struct Buffer {
@@ -106,12 +128,24 @@ __global__ __launch_bounds__(256) void k_update_phase(PbDevParams P, const float
   phase[i] = pbPhase(P, p.x, p.y, spacing, min_d, phase[i]);
 }
 
-// impl.cuh:36-41 (state = (seed, draw counter) per bot)
-__global__ __launch_bounds__(256) void k_rng_setup(pbRngState *__restrict__ st, uint32_t seed, uint32_t n) {
+// impl.cuh:36-41.  Counter generator: state = (seed, draws so far).  XORWOW kinds: curand_init(seed, i, 0).
+__global__ __launch_bounds__(256) void k_rng_setup(pbRngState *__restrict__ st, uint32_t seed, uint32_t n, int kind,
+                                                   const uint32_t *__restrict__ jump) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  st[i].seed = seed;
-  st[i].draw = 0;
+  pbRngState s;
+  if (kind == PB_RNG_COUNTER) {
+    s.d = seed;
+    s.v[0] = s.v[1] = s.v[2] = s.v[3] = s.v[4] = 0u;
+    s.boxmuller_flag = 0;
+    s.kind = PB_RNG_COUNTER;
+    s.boxmuller_extra = 0.0f;
+    s.reserved[0] = s.reserved[1] = s.reserved[2] = 0.0f;
+  } else {
+    pbXorwowSeed(s, (uint64_t)seed, kind);
+    pbXorwowSkipSubsequences(s, i, jump);
+  }
+  st[i] = s;
 }
 
 // impl.cuh:43-51
@@ -120,9 +154,14 @@ __global__ __launch_bounds__(256) void k_add_noise(pbRngState *__restrict__ st, 
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   pbRngState s = st[i];
-  const float noise = std * pbNormal(s.seed, i, s.draw);
+  float noise;
+  if (s.kind == PB_RNG_COUNTER) {
+    noise = std * pbNormal(s.d, i, s.v[0]);
+    s.v[0] += 1;
+  } else {
+    noise = std * pbXorwowNormal(s);
+  }
   val[i] += noise;
-  s.draw += 1;
   st[i] = s;
 }
 
@@ -334,10 +373,24 @@ void updateRad_light_wave(float *, float *absForce_a, float *absForce_r, float *
   PB_CHECK_ABORT(hipGetLastError());
 }
 
+int pbSetRngKind(int kind) {
+  if (kind != PB_RNG_COUNTER && kind != PB_RNG_XORWOW_CURAND && kind != PB_RNG_XORWOW_ROCRAND) return 1;
+  g_rngKind = kind;
+  return 0;
+}
+
+int pbGetRngKind(void) { return g_rngKind; }
+
 void curand_setup(pbRngState *state, int N) {
   requireParams("curand_setup");
   if (N <= 0) return;
-  hipLaunchKernelGGL(k_rng_setup, gridFor(N, 256), dim3(256), 0, 0, state, g_P.seed, (uint32_t)N);
+  const uint32_t *jump = nullptr;
+  if (g_rngKind != PB_RNG_COUNTER) {
+    hipError_t e = hipSuccess;
+    jump = pbXorwowDeviceTable(&e);
+    PB_CHECK_ABORT(e);
+  }
+  hipLaunchKernelGGL(k_rng_setup, gridFor(N, 256), dim3(256), 0, 0, state, g_P.seed, (uint32_t)N, g_rngKind, jump);
   PB_CHECK_ABORT(hipGetLastError());
 }
 

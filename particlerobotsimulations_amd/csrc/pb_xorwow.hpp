@@ -188,7 +188,6 @@ PB_XW_HD float pbXorwowNormal(pbRngState &s) {
 }
 
 // ---- host side: the jump table -------------------------------------------------------------------
-#if !defined(__HIP_DEVICE_COMPILE__)
 #include <vector>
 
 // table[k] = T^(2^67 * 2^k) for the one-step matrix T of pbXorwowShift, k = 0..31, built by repeated
@@ -216,4 +215,3 @@ inline void pbXorwowBuildJumpTable(uint32_t *table) {
     if (k + 1 < PB_XW_TABLE_MATS) square();
   }
 }
-#endif

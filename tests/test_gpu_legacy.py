@@ -173,7 +173,9 @@ def test_noise_matches_oracle_rng(pb, orc):
     n = 200000
     P = orc.default_params(nCells=n, nDead=0, seed=987654321)
     keep = upload_params(pb, P)
-    state = pb.DeviceArray(2 * n, np.uint32)
+    from particlerobotsimulations_amd import _capi
+    state = pb.DeviceArray(12 * n, np.uint32)  # sizeof(pbRngState) = 48 bytes, as sizeof(curandState)
+    assert _capi.lib().pbSetRngKind(0) == 0
     pb.legacy.rng_setup(state, n)
     val = np.zeros(n, np.float32)
     dval = pb.DeviceArray.from_host(val)
@@ -182,6 +184,20 @@ def test_noise_matches_oracle_rng(pb, orc):
         pb.legacy.add_noise(state, dval, 0.6, n)
         orc.lib().orc_add_normal_noise(P.seed, draw, oval, 0.6, n)
         assert_bit_equal(dval.download(), oval, f"after draw {draw}")
+    # the same boundary with the cuRAND-compatible XORWOW generator (curand_init(seed, i, 0) per bot,
+    # curand_normal per call: the pair's second value is cached in the 48-byte state)
+    assert _capi.lib().pbSetRngKind(1) == 0 and _capi.lib().pbGetRngKind() == 1
+    pb.legacy.rng_setup(state, n)
+    dval = pb.DeviceArray.from_host(val)
+    for draw in range(3):
+        pb.legacy.add_noise(state, dval, 0.6, n)
+    z = np.zeros((3, n), np.float32)
+    orc.lib().orc_xorwow_normals(1, P.seed, n, 3, z)
+    want = val.copy()
+    for draw in range(3):
+        want = want + (np.float32(0.6) * z[draw]).astype(np.float32)
+    assert_bit_equal(dval.download(), want, "xorwow noise through the legacy boundary")
+    assert _capi.lib().pbSetRngKind(7) != 0 and _capi.lib().pbSetRngKind(0) == 0
     one = np.zeros(n, np.float32)
     orc.lib().orc_add_normal_noise(P.seed, 7, one, 1.0, n)
     assert abs(one.mean()) < 0.01 and abs(one.std() - 1.0) < 0.01
