@@ -293,6 +293,38 @@ def large_arena_leg(pb, pitch, warmup, steps, n=8_000_000):
             "note": "working set beyond the Infinity Cache: if HBM bound the step would cost > 8x the 10^6-bot one"}
 
 
+def blob_leg(pb, n, steps, warmup):
+    """the same arena holding a RANDOM BLOB of n bots grown by the reference's placement
+    rule with the O(N) generator (`pb_placement fastblob`, Particlebot::placeFastBlob) instead of the
+    lattice: the reference's own kind of initial state at a size its O(N^1.5) loop cannot reach."""
+    import numpy as np
+    from particlerobotsimulations_amd import host
+    t0 = time.perf_counter()
+    h = host.HostSim(os.path.join(ROOT, "examples", "million_bot_blob.cfg"), engine="host", nCells=str(n))
+    place_s = time.perf_counter() - t0
+    pos = h.get("pos")
+    h.close()
+    sp, keep = workload_params(n, seed=1)
+    sim = pb.Sim(sp, wall_half=240.0, keepalive=keep)
+    sim.set_force_variant(2)
+    sim.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
+                  phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
+    sim.step(warmup)
+    done, ms = sim.step_timed(steps)
+    st = sim.get_state()
+    cx, cy = sim.centroid()
+    sim.close()
+    us = ms * 1e3 / max(done, 1)
+    achieved = ALG_BYTES_PER_PARTICLE_STEP * n / (us * 1e-6) / 1e9
+    return {"bots": n, "placement": "pb_placement fastblob (examples/million_bot_blob.cfg)", "placement_s": place_s,
+            "steps": done, "warmup": warmup, "us_per_step": us, "value": n * done / (ms * 1e-3),
+            "unit": "particle-steps/s (device time)", "finite_at_end": bool(cx == cx and cy == cy),
+            "bots_in_contact_frac": float((st["absForce_r"] > 0).mean()),
+            "max_speed": float(np.abs(st["vel"]).max()),
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS}}
+
+
 # ---- ensemble workloads (BASELINE configs[3] and configs[4]) -------------------------------------
 ENSEMBLE_WORKLOADS = {
     # name -> list of batches: (cfg, common overrides, per-member override maker)
@@ -486,6 +518,7 @@ def main():
     ap.add_argument("--no-streamlined", action="store_true")
     ap.add_argument("--no-large-arena", action="store_true")
     ap.add_argument("--no-clock", action="store_true")
+    ap.add_argument("--no-blob", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the cpu_baseline sample")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path")
@@ -611,6 +644,8 @@ def main():
         sim.close()
         if world == 1 and not args.no_large_arena:
             out["large_arena"] = large_arena_leg(pb, args.pitch, 20, min(args.steps, 200))
+        if world == 1 and not args.no_blob:
+            out["random_blob"] = blob_leg(pb, n, min(args.steps, 600), args.warmup)
         if world == 1 and not args.no_survey_literal:
             out["survey_literal_lattice"] = survey_literal(pb, n, args.steps, args.warmup)
         if world == 1 and not args.no_streamlined:

@@ -103,6 +103,11 @@ class Particlebot {
    * params.config says.  Unlike any hexagonal packing, four contacts per bot are numerically stable
    * under the reference's parameters: the O(N) placement for very large arenas. */
   void setSquareLattice(bool on) { squareLattice = on; }
+  /* Extension (`pb_placement fastblob`): a random blob grown by the reference's rule (random anchor,
+   * random angle, pivot to contact; particlebot.cpp:612-748) with the anchors drawn from the discs
+   * that still have room: O(N), for blobs the reference's O(N^1.5) loop cannot reach (10^6 bots in
+   * seconds).  Same kind of blob, different random stream: NOT the reference's placement. */
+  void setFastBlob(bool on) { fastBlob = on; }
   /* Extension: phase-noise generator, PB_RNG_* of particlebot_hip.h (default PB_RNG_COUNTER; the
    * `pb_rng` key of a .cfg: "pbrng", "curand" or "rocrand").  Re-initialises the per-bot generator
    * states, as curand_setup does at construction (particlebot.cpp:165); call it before the first step. */
@@ -149,6 +154,7 @@ class Particlebot {
   void initGrid(uint2 size, float spacing, float jitter, uint numParticles);
   void initHexGrid(uint numParticles, float spacing);
   void placeRandom();
+  void placeFastBlob();
   void drawDeadBots();
   void pullState(bool pos, bool vel, bool rad);
   void legacyUpdate(float deltaTime, float sort_interval);
@@ -182,6 +188,7 @@ class Particlebot {
   bool exitOnMaxTime = true;
   float hexSpacing = 0.0f;
   bool squareLattice = false;
+  bool fastBlob = false;
   int rngKindV = 0; /* PB_RNG_COUNTER */
   PbLibcRand rng; /* seeded with params.seed at construction */
 };

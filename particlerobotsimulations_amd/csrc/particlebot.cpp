@@ -39,29 +39,39 @@ void die(const char *what) {
 struct PlacementGrid {
   uint gx, gy;
   float ox, oy, cx, cy;
-  std::vector<int> head, next;
+  // one node per placed disc: its position travels with the chain link, so walking a cell's list
+  // touches one cache line per disc (the lists are walked ~100 times per placed disc)
+  struct Node {
+    float x, y;
+    int next;
+  };
+  std::vector<int> head;
+  std::vector<Node> node;
   PlacementGrid(const SimParams &p, uint n)
       : gx(p.gridSize.x), gy(p.gridSize.y), ox(p.worldOrigin.x), oy(p.worldOrigin.y), cx(p.cellSize.x),
-        cy(p.cellSize.y), head((size_t)p.gridSize.x * p.gridSize.y, -1), next(n, -1) {}
+        cy(p.cellSize.y), head((size_t)p.gridSize.x * p.gridSize.y, -1), node(n) {}
   int col(float x) const { return ((int)floorf((x - ox) / cx)) & (int)(gx - 1); }
   int row(float y) const { return ((int)floorf((y - oy) / cy)) & (int)(gy - 1); }
-  void add(int bot, float x, float y) {
+  // bin disc `bot` under the cell of (x, y); (px, py) is where it really is (they differ only for the
+  // reference's seed disc, particlebot.cpp:635-637)
+  void add(int bot, float x, float y, float px, float py) {
     const size_t c = (size_t)col(x) * gy + (size_t)row(y);
-    next[bot] = head[c];
+    node[bot] = Node{px, py, head[c]};
     head[c] = bot;
   }
+  void add(int bot, float x, float y) { add(bot, x, y, x, y); }
   // any listed bot within `limit` of (x,y) in the 3x3 cells around it?
   // The decision is the reference's `length(...) < limit` with its three powf calls; a double
   // precision squared distance settles every pair that is not within 1e-5 (relative) of the limit
   // -- hostLength is good to a few 1e-7 -- so the powf form only runs for pairs that (nearly) touch.
-  bool crowded(float x, float y, const float *pos, double limit) const {
+  bool crowded(float x, float y, double limit) const {
     const int xc = col(x), yc = row(y);
     const double far2 = limit * limit * (1.0 + 2e-5), near2 = limit * limit * (1.0 - 2e-5);
     for (int xg = xc - 1; xg <= xc + 1; xg++)
       for (int yg = yc - 1; yg <= yc + 1; yg++) {
         if (xg < 0 || yg < 0 || xg >= (int)gx || yg >= (int)gy) continue;
-        for (int b = head[(size_t)xg * gy + yg]; b >= 0; b = next[b]) {
-          const float dx = x - pos[2 * b], dy = y - pos[2 * b + 1];
+        for (int b = head[(size_t)xg * gy + yg]; b >= 0; b = node[b].next) {
+          const float dx = x - node[b].x, dy = y - node[b].y;
           const double d2 = (double)dx * dx + (double)dy * dy;
           if (d2 > far2) continue;
           if (d2 < near2 || hostLength(dx, dy) < limit) return true;
@@ -587,7 +597,7 @@ void Particlebot::placeRandom() {
   float lowestX = 9999999.0;
   hPos[0] = 5.0;
   hPos[1] = 0.0;
-  grid.add(0, 0.0f, 0.0f);  // sic: the reference bins bot 0 at the origin's cell (:635-637)
+  grid.add(0, 0.0f, 0.0f, hPos[0], hPos[1]);  // sic: the reference bins bot 0 at the origin's cell (:635-637)
   float x = 0, y = 0;
   for (uint i = 1; i < n; i++) {
     if (g_verbosePlacement) printf("Placing %d th disc\n", i);
@@ -616,7 +626,7 @@ void Particlebot::placeRandom() {
       float theta = 2 * frand(rng) * kPi;
       x = hPos[2 * anchor] + 2 * r * cosf(theta);
       y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
-      if (grid.crowded(x, y, hPos, touch)) {
+      if (grid.crowded(x, y, touch)) {
         rejections++;
         continue;
       }
@@ -625,7 +635,7 @@ void Particlebot::placeRandom() {
         theta += pivot;
         x = hPos[2 * anchor] + 2 * r * cosf(theta);
         y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
-        if (grid.crowded(x, y, hPos, touch)) {
+        if (grid.crowded(x, y, touch)) {
           theta -= pivot;
           break;
         }
@@ -642,6 +652,86 @@ void Particlebot::placeRandom() {
     hPos[2 * i] = x;
     hPos[2 * i + 1] = y;
     grid.add((int)i, x, y);
+  }
+}
+
+void Particlebot::placeFastBlob() {
+  // Extension (`pb_placement fastblob`): the same growth process as placeRandom -- a new disc is hung on
+  // a random already-placed anchor at a random angle, rejected if crowded, then pivoted in 10-degree
+  // steps until it is about to touch something (particlebot.cpp:676-726) -- in O(N) instead of
+  // O(N^1.5).  The reference draws the anchor uniformly from ALL placed discs, and in a blob of i discs
+  // only the ~sqrt(i) on its rim have room, so nearly every draw is wasted on an interior disc.  Here
+  // anchors come from a list of discs that may still have room (a disc leaves it after kMaxFails
+  // crowded attempts in a row), so the accepted anchors are distributed as the reference's accepted
+  // anchors are; the wasted interior draws are only COUNTED, because the reference's rejection counter
+  // widens the ring (r += min_radius every 200 rejections, :626-629) and that shapes large blobs.
+  // Different random stream => a different blob of the same kind, not the reference's blob: the
+  // default stays placeRandom (parity); tests hold this one to placeRandom's statistics.
+  const uint n = params.nCells;
+  if (n == 0) return;
+  PlacementGrid grid(params, n);
+  particlebotConfigSize.x = (int)ceilf(powf((float)n, 1.0f / 2.0f));
+  const double touch = 2 * 1.0 * params.min_radius;
+  const float pivot = 2 * kPi / 360.0 * 10.0;
+  const int kMaxFails = 16;
+  double rejections = 0.0;  // the reference's cumulative counter, interior draws included (expected value)
+  float lowestX = 9999999.0;
+  hPos[0] = 5.0;
+  hPos[1] = 0.0;
+  grid.add(0, hPos[0], hPos[1]);
+  std::vector<uint> open(1, 0u);
+  std::vector<unsigned char> fails(n, 0);
+  float x = 0, y = 0;
+  for (uint i = 1; i < n; i++) {
+    float r = params.min_radius;
+    for (;;) {
+      if (open.empty()) {  // every disc looked full: widen the ring and look at all of them again
+        r += params.min_radius;
+        for (uint k = 0; k < i; k++) open.push_back(k);
+        std::fill(fails.begin(), fails.begin() + i, 0);
+      }
+      const size_t slot = (size_t)((uint)rng.next() % (uint)open.size());
+      const uint anchor = open[slot];
+      rejections += (double)i / (double)open.size() - 1.0;
+      if (rejections >= 200.0) {
+        rejections -= 200.0;
+        r += params.min_radius;
+      }
+      float theta = 2 * frand(rng) * kPi;
+      x = hPos[2 * anchor] + 2 * r * cosf(theta);
+      y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
+      if (grid.crowded(x, y, touch)) {
+        rejections += 1.0;
+        if (r == params.min_radius && ++fails[anchor] >= kMaxFails) {
+          open[slot] = open.back();
+          open.pop_back();
+        }
+        continue;
+      }
+      fails[anchor] = 0;
+      const float theta0 = theta;
+      while (theta - theta0 < 2 * kPi) {
+        theta += pivot;
+        x = hPos[2 * anchor] + 2 * r * cosf(theta);
+        y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
+        if (grid.crowded(x, y, touch)) {
+          theta -= pivot;
+          break;
+        }
+      }
+      x = hPos[2 * anchor] + 2 * r * cosf(theta);
+      y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
+      break;
+    }
+    if (x < lowestX) lowestX = x;
+    if (params.nDead == -1 && i == n - 1) {  // the payload sits left of the blob (:731-735)
+      x = lowestX - 1 * params.min_radius * params.radFactor - 2 * params.min_radius;
+      y = 0;
+    }
+    hPos[2 * i] = x;
+    hPos[2 * i + 1] = y;
+    grid.add((int)i, x, y);
+    open.push_back(i);
   }
 }
 
@@ -663,6 +753,8 @@ void Particlebot::reset() {
       hPos[2 * i + 1] = ((float)(i / side) - half) * pitch;
     }
     particlebotConfigSize.x = particlebotConfigSize.y = side;
+  } else if (fastBlob) {
+    placeFastBlob();
   } else
   switch (params.config) {
     case CONFIG_HEX:

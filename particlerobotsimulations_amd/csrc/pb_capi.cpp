@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "particlebot.h"
+#include "particlebot_ensemble.h"
 #include "pb_config.hpp"
 #include "pb_xorwow.hpp"
 
@@ -187,6 +188,7 @@ void *pbHostCreate(const char *cfg_path, const char *overrides, int engine) {
   h->bot->setExitOnMaxTime(false);
   h->bot->setHexSpacing(h->cfg.hex_spacing);
   h->bot->setSquareLattice(h->cfg.square_lattice);
+  h->bot->setFastBlob(h->cfg.fast_blob);
   h->bot->setRng(h->cfg.rng_kind);
   return h;
 }
@@ -346,6 +348,7 @@ void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const
       Particlebot *bot = new Particlebot(cfg->params, Particlebot::Engine::HostOnly, cfg->wallHalf());
       bot->setHexSpacing(cfg->hex_spacing);
       bot->setSquareLattice(cfg->square_lattice);
+      bot->setFastBlob(cfg->fast_blob);
       bot->setRng(cfg->rng_kind);
       bot->reset();
       e->bots[k] = bot;
@@ -466,6 +469,24 @@ long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
 }
 
 int pbEnsembleSynchronize(void *ev) { return pbSimSynchronize(((Ensemble *)ev)->sim); }
+
+int pbEnsembleShard(int nmembers, int rank, int world) {
+  if (nmembers < 0 || world < 1 || rank < 0 || rank >= world) return 0;
+  return (nmembers - rank + world - 1) / world;  // members rank, rank + world, ... below nmembers
+}
+
+int pbEnsembleAssemble(int nmembers, int world, int rows, const float *gathered, float *out) {
+  if (nmembers < 0 || world < 1 || rows < 0 || !gathered || !out) return 1;
+  const int per = pbEnsembleShard(nmembers, 0, world);
+  const size_t rowFloats = (size_t)rows * 4;
+  for (int r = 0; r < world; r++) {
+    const int mine = pbEnsembleShard(nmembers, r, world);
+    for (int j = 0; j < mine; j++)
+      memcpy(out + (size_t)(r + j * world) * rowFloats, gathered + ((size_t)r * per + j) * rowFloats,
+             sizeof(float) * rowFloats);
+  }
+  return 0;
+}
 
 int pbEnsembleGetState(void *ev, int member, float *pos, float *vel, float *rad) {
   Ensemble *e = (Ensemble *)ev;

@@ -68,6 +68,7 @@ PbRunConfig::PbRunConfig() {
   arena_half = 0.0f;
   hex_spacing = 0.0f;
   square_lattice = false;
+  fast_blob = false;
   rng_kind = 0;
   repoint();
 }
@@ -180,6 +181,7 @@ void PbRunConfig::setParam(const std::string &name, const std::string &value) {
   else if (is("pb_hex_spacing", 14)) hex_spacing = f();
   else if (is("pb_placement", 12)) {
     square_lattice = value.rfind("square", 0) == 0;
+    fast_blob = value.rfind("fastblob", 0) == 0;
     if (value.rfind("hex", 0) == 0) params.config = CONFIG_HEX;
     else if (value.rfind("grid", 0) == 0) params.config = CONFIG_GRID;
     else if (value.rfind("line", 0) == 0) params.config = CONFIG_LINE;

@@ -20,6 +20,7 @@ struct PbRunConfig {
   float arena_half;    // 0 -> walls and world origin at +-64 (main.cpp:939, impl.cuh:75-97)
   float hex_spacing;   // 0 -> 2*min_radius (particlebot.cpp:760); lattice pitch of hex / square placement
   bool square_lattice; // pb_placement square
+  bool fast_blob;      // pb_placement fastblob: O(N) random blob (Particlebot::placeFastBlob)
   int rng_kind;        // pb_rng: PB_RNG_COUNTER ("pbrng", default), PB_RNG_XORWOW_CURAND ("curand"), PB_RNG_XORWOW_ROCRAND ("rocrand")
 
   PbRunConfig();

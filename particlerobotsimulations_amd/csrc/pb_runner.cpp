@@ -67,6 +67,7 @@ int main(int argc, char **argv) {
   sim.setExitOnMaxTime(false);
   sim.setHexSpacing(cfg.hex_spacing);
   sim.setSquareLattice(cfg.square_lattice);
+  sim.setFastBlob(cfg.fast_blob);
   sim.setRng(cfg.rng_kind);
   sim.reset();
   const SimParams &p = sim.getParams();

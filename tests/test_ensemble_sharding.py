@@ -69,3 +69,50 @@ def test_gather_single_rank_is_identity():
     from particlerobotsimulations_amd.ensemble import gather_summaries
     x = np.random.default_rng(0).random((3, 4, 4)).astype(np.float32)
     assert gather_summaries(x, 3, 0, 1) is x
+
+
+# ---- the C++ side of the same layer (include/particlebot_ensemble.h; bin/particlebot_ensemble) ----
+
+@pytest.mark.parametrize("n_members,world", [(7, 2), (8, 2), (256, 8), (1024, 8), (3, 8), (5, 1)])
+def test_cxx_shard_and_assemble_agree_with_the_python_layer(n_members, world):
+    """pbEnsembleShard / pbEnsembleAssemble (what the RCCL runner uses after its ncclAllGather) against
+    ensemble.shard and the layout gather_summaries produces: the gathered buffer is built here exactly
+    as an all-gather of equal NaN-padded blocks leaves it."""
+    import ctypes as C
+
+    from particlerobotsimulations_amd import host
+    from particlerobotsimulations_amd.ensemble import shard
+    L = host.lib()
+    L.pbEnsembleShard.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.pbEnsembleAssemble.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rows = 3
+    per = L.pbEnsembleShard(n_members, 0, world)
+    assert per == len(shard(n_members, 0, world))
+    gathered = np.full((world, per, rows, 4), np.nan, np.float32)
+    for r in range(world):
+        ids = shard(n_members, r, world)
+        assert L.pbEnsembleShard(n_members, r, world) == len(ids)
+        for j, k in enumerate(ids):
+            gathered[r, j] = _fake_rows(k, rows)
+    out = np.full((n_members, rows, 4), -1.0, np.float32)
+    assert L.pbEnsembleAssemble(n_members, world, rows, gathered.ctypes.data_as(C.c_void_p),
+                                out.ctypes.data_as(C.c_void_p)) == 0
+    want = np.stack([_fake_rows(k, rows) for k in range(n_members)]).astype(np.float32)
+    assert np.array_equal(out, want)
+
+
+def test_cxx_runner_fails_loudly_without_a_gpu_or_arguments():
+    """bin/particlebot_ensemble: usage error without a configuration; and on a machine without a GPU a
+    clear error and a nonzero exit (never a CPU fallback)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "particlerobotsimulations_amd", "bin", "particlebot_ensemble")
+    if not os.path.exists(exe):
+        pytest.skip("runner not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "--members" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, os.path.join(root, "examples", "example_dead_cells.cfg"), "--members", "2"],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and ("HIP" in r.stderr or "device" in r.stderr), r.stderr

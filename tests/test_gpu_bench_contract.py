@@ -37,3 +37,41 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     s = d["streamlined"]
     assert s["finite_at_end"] and s["value"] > d["value"] and s["parity"]["window_steps"] == 10
+
+
+def _bench(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+
+
+def test_ensemble_workload_line_and_rccl_path_on_one_gpu():
+    """`bench.py --workload ensemble4` (BASELINE configs[3]: obstacle + object-transport seed ensembles)
+    under the same contract keys; with --force-dist the same command initialises RCCL (world size 1),
+    runs the max-over-ranks all_reduce and the all_gather of the summary rows, and must report the
+    SAME summaries."""
+    common = ("--workload", "ensemble4", "--members-per-gpu", "6", "--steps", "700", "--warmup", "50",
+              "--cpu-seconds", "1")
+    a = _bench(*common)
+    b = _bench(*common, "--force-dist", "--no-cpu-baseline")
+    for d in (a, b):
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "sims_per_s"):
+            assert k in d, k
+        assert d["n_gpus"] == 1 and d["steps"] == 700 and d["scaling"] == "weak" and d["unit"] == "particle-steps/s"
+        assert d["config"]["members_per_gpu"] == 12 and d["config"]["bots_per_member"] == [500, 201]
+        assert d["config"]["members_per_rank"] == [12]
+        assert abs(d["value"] - 6 * (500 + 201) * 700 / (d["ms_per_step"] * 700 * 1e-3)) / d["value"] < 1e-6
+        assert d["summary_rows_gathered"] == [[6, 3, 4], [6, 3, 4]]   # rows at t = 0, 0.01 and 6.0
+    assert "RCCL world size 1" in b["config"]["parallelism"]
+    assert a["summaries_last_row_time_comx_comy_dist"] == b["summaries_last_row_time_comx_comy_dist"]
+    assert a["cpu_baseline"]["kind"] == "port" and a["cpu_baseline"]["value"] > 0
+
+
+def test_ensemble5_workload_line():
+    """BASELINE configs[4] at bench scale: 10^5-bot members of the dead-fraction sweep as one batch."""
+    d = _bench("--workload", "ensemble5", "--members-per-gpu", "2", "--steps", "60", "--warmup", "10",
+               "--no-cpu-baseline")
+    assert d["config"]["bots_per_member"] == [100000] and d["config"]["members_per_gpu"] == 2
+    assert d["value"] > 1e8 and d["summary_rows_gathered"] == [[2, 2, 4]]

@@ -288,3 +288,25 @@ def test_random_cfg_files_end_to_end(host, orc, tmp_path, trial):
     for k in ("pos", "vel", "rad", "phase"):
         assert_bit_equal(gsim.get(k), osim.get(k), k)
     assert_bit_equal(gsim.get("dead"), osim.get("dead"), "dead")
+
+
+def test_cxx_rccl_ensemble_runner_equals_python_layer(tmp_path):
+    """bin/particlebot_ensemble (C++ only: pbEnsemble* + one ncclAllGather over RCCL, here a world of
+    one rank) writes the same summary rows as ensemble.run_local for the same members."""
+    import json
+    from particlerobotsimulations_amd import ensemble
+    exe = os.path.join(ROOT, "particlerobotsimulations_amd", "bin", "particlebot_ensemble")
+    cfg = EX("example_dead_cells.cfg")
+    out = tmp_path / "rows.f32"
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([exe, cfg, "--members", "6", "--seed0", "500", "--set", "max_time", "1.55", "--set",
+                        "dump_interval", "0.5", "--sweep", "nDead", "0", "10", "20", "--out", str(out)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    info = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert info["members"] == 6 and info["n_gpus"] == 1 and info["bots_per_member"] == 100
+    got = np.fromfile(out, np.float32).reshape(6, info["rows_per_member"], 4)
+    over = [ensemble.member_overrides(k, 500, ("nDead", ["0", "10", "20"])) for k in range(6)]
+    rows, steps = ensemble.run_local(cfg, over, {"max_time": "1.55", "dump_interval": "0.5"})
+    assert steps == info["steps_per_member"]
+    assert np.array_equal(got, rows)

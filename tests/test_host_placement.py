@@ -134,3 +134,67 @@ def test_tiny_placements_match_oracle(host, orc, n):
     o = orc.Sim(P)
     for k in ("pos", "vel", "rad", "phase"):
         assert_bit_equal(h.get(k), o.get(k), f"n={n} {k}")
+
+
+# ---- pb_placement fastblob: the O(N) random-blob generator ---------------------
+
+def _blob_stats(pos, origin=-64.0, cell=0.235):
+    """contacts per bot (pairs at 2 r_min), radius of gyration, mean candidate pairs in the 5x5 stencil"""
+    from collections import Counter
+
+    from scipy.spatial import cKDTree
+    pos = pos.astype(np.float64)
+    n = len(pos)
+    tree = cKDTree(pos)
+    contacts = 2.0 * len(tree.query_pairs(2 * 0.0775 * 1.001)) / n
+    overlaps = len(tree.query_pairs(2 * 0.0775 * 0.999))
+    rg = float(np.sqrt(((pos - pos.mean(0)) ** 2).sum(1).mean()))
+    cx = np.floor((pos[:, 0] - origin) / cell).astype(int)
+    cy = np.floor((pos[:, 1] - origin) / cell).astype(int)
+    cnt = Counter(zip(cx.tolist(), cy.tolist()))
+    tot = 0
+    for (x, y), k in cnt.items():
+        tot += k * (sum(cnt.get((x + dx, y + dy), 0) for dx in range(-2, 3) for dy in range(-2, 3)) - 1)
+    return contacts, rg, tot / n, overlaps
+
+
+def test_fastblob_matches_reference_rule_statistics(host):
+    """At 10^4 bots the fast generator's blobs are the reference rule's blobs statistically: contacts
+    per bot, radius of gyration and the force kernel's candidate pairs per bot (42 +- 2), seed by seed
+    within the seed-to-seed spread x a small factor."""
+    ex = os.path.join(ROOT, "examples", "example.cfg")
+    ref, fast = [], []
+    for seed in (11, 12, 13):
+        a = host.HostSim(ex, engine="host", nCells="10000", seed=str(seed))
+        b = host.HostSim(ex, engine="host", nCells="10000", seed=str(seed), pb_placement="fastblob")
+        ref.append(_blob_stats(a.get("pos")))
+        fast.append(_blob_stats(b.get("pos")))
+        assert not np.array_equal(a.get("pos"), b.get("pos"))  # a different blob of the same kind
+    ref, fast = np.array(ref), np.array(fast)
+    assert abs(fast[:, 0].mean() - ref[:, 0].mean()) < 0.05 * ref[:, 0].mean(), (ref, fast)   # contacts per bot
+    assert abs(fast[:, 1].mean() - ref[:, 1].mean()) < 0.02 * ref[:, 1].mean(), (ref, fast)   # radius of gyration
+    assert abs(ref[:, 2].mean() - 42.0) < 2.0 and abs(fast[:, 2].mean() - 42.0) < 2.0, (ref, fast)
+    assert abs(fast[:, 2].mean() - ref[:, 2].mean()) < 1.5
+    # no real overlaps (the reference's own blob has the bot-2 / bot-0 quirks: a handful)
+    assert fast[:, 3].max() <= 3 and ref[:, 3].max() <= 3
+
+
+def test_fastblob_is_deterministic_linear_and_handles_the_payload(host):
+    import time
+    ex = os.path.join(ROOT, "examples", "example_object_transport.cfg")
+    a = host.HostSim(ex, engine="host", pb_placement="fastblob")
+    b = host.HostSim(ex, engine="host", pb_placement="fastblob")
+    assert_bit_equal(a.get("pos"), b.get("pos"), "same seed, same blob")
+    pos = a.get("pos")
+    assert pos[-1, 1] == 0.0 and pos[-1, 0] < pos[:-1, 0].min()  # payload left of the blob (particlebot.cpp:731-735)
+    # roughly linear in N: 10x the bots within ~25x the time even on a noisy box (the reference rule: ~32x)
+    big = dict(pb_grid_size="2048", pb_arena_half="240")
+    t = []
+    for n in (20000, 200000):
+        t0 = time.perf_counter()
+        s = host.HostSim(os.path.join(ROOT, "examples", "example.cfg"), engine="host", nCells=str(n),
+                         pb_placement="fastblob", **big)
+        t.append(time.perf_counter() - t0)
+        p = s.get("pos")
+        assert np.isfinite(p).all() and np.abs(p).max() < 240.0
+    assert t[1] < 25 * t[0] + 0.5, t

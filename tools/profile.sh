@@ -4,7 +4,7 @@
 # usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-run}; shift || true
-ARGS=${@:---steps 400 --warmup 100 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock}
+ARGS=${@:---steps 400 --warmup 100 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
