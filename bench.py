@@ -223,14 +223,14 @@ def profiled_traffic():
 
 SIMDS = 1024                 # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md)
 DATASHEET_CYC_SIMPLE = 2.0   # cycles per wave64 VALU instruction per SIMD ("v_fma_f32 (wave64) 2 cyc")
-DATASHEET_CYC_TRANS = 4.0    # v_rcp/v_sqrt/v_rsq: twice a simple one (the guide's single-wave issue costs 8 : 4)
+DATASHEET_CYC_TRANS = 8.0    # v_rcp/v_sqrt/v_rsq: quarter rate (8 lanes/clk; the guide's issue cost 8; tools/valu_rate measures 9.1-9.3)
 NOMINAL_MHZ = 2400.0
 
 
 def valu_roofline(tr, n, avg_launch_us, clock_mhz):
     """The force kernel's VALU instruction stream (PMC counts per wave from the committed profile)
     priced two ways against this run's launch time: (a) at the datasheet issue rate -- 2 cycles per
-    wave64 instruction per SIMD-32, 4 for a transcendental -- at the shader clock MEASURED under this
+    wave64 instruction per SIMD-32, 8 for a quarter-rate transcendental -- at the shader clock MEASURED under this
     load (and, for reference, at the 2.4 GHz nominal clock); (b) at the rates tools/valu_rate measured
     on the profiled box at 8 waves per SIMD."""
     if not tr or "valu_insts_per_wave" not in tr or "trans_per_wave" not in tr:

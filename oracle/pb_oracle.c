@@ -1202,13 +1202,13 @@ static void place_random(OrcSim *s) {
 
 /* particlebot.cpp:438-481 initHexGrid (unreachable from a .cfg in the reference; used here for
  * the synthetic large-arena workload) */
-static void place_hex(OrcSim *s, float spacing) {
+static int place_hex(OrcSim *s, float spacing) { /* returns particlebotConfigSize.x (:479) */
   const uint32_t n = s->n;
   float *hPos = s->pos;
   const float h = powf(3, 0.5f) * 0.5f;
   const float dirs[7][3] = {{1.0, 0.0, 0.0}, {0.5, 0.0, h},   {-0.5, 0.0, h}, {-1.0, 0.0, 0.0},
                             {-0.5, 0.0, -h}, {0.5, 0.0, -h}, {1.0, 0.0, 0.0}};
-  if (n == 0) return;
+  if (n == 0) return 2;
   uint32_t i = 0;
   hPos[0] = 0.0f;
   hPos[1] = 0.0f;
@@ -1226,6 +1226,7 @@ static void place_hex(OrcSim *s, float spacing) {
     }
     n_ring++;
   }
+  return n_ring * 2;
 }
 
 void orc_sim_reset(OrcSim *s, int use_hex) {
@@ -1235,10 +1236,16 @@ void orc_sim_reset(OrcSim *s, int use_hex) {
   s->time = 0;
   s->phaseDraws = 0;
   memset(s->vel, 0, 8 * (size_t)n);
-  if (use_hex)
-    place_hex(s, P->min_radius * 2.0f);
-  else
+  int configSizeX; /* particlebotConfigSize.x */
+  if (use_hex) {
+    configSizeX = place_hex(s, P->min_radius * 2.0f); /* :759-760, then :479 inside initHexGrid */
+  } else {
     place_random(s);
+    configSizeX = (int)ceilf(powf((float)n, 1.0f / 2.0f)); /* :624 */
+  }
+  /* particlebot.cpp:772-773: a zero Nx (unreachable from a .cfg, reachable through SimParams) falls
+   * back to particlebotConfigSize.x */
+  if (!s->P.Nx) s->P.Nx = configSizeX;
   for (uint32_t i = 0; i < n; i++) {
     s->rad[i] = P->min_radius;
     if (P->nDead == -1 && i == n - 1) {

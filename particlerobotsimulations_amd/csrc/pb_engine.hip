@@ -31,6 +31,7 @@
 //    workgroup per simulation, state in registers/LDS, many timesteps per launch).
 //  * k_force_stream is the one kernel that is NOT bit-identical: the opt-in streamlined arithmetic
 //    of force variant 3.
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -477,6 +478,13 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
   pbSweepC<PAYLOAD, FLAT, FAST, L, NB, false>(P, prIn, velIn, cellS, base, s, sub, me, v, att1, F, none);
 }
 
+#ifdef PB_TIMELINE
+// Diagnostic build only (-DPB_TIMELINE, tools/timeline.py): every workgroup of k_force stamps the
+// 100 MHz real-time counter when it starts and when it ends, with the XCD and CU it ran on, into a
+// buffer set by pbDebugSetTimeline.  Never compiled into the shipped library.
+__device__ unsigned long long *pbTimelineBuf = nullptr;
+#endif
+
 // Forces + kick of step n (impl.cuh:657-831); with FUSE also radius + integration of step n+1.
 // PAYLOAD: object-transport mode (nDead == -1), per-pair attraction factors.  FLAT: branch-free
 // pair evaluation instead of the reference-shaped branches (pbPair).
@@ -498,6 +506,11 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
   const uint32_t tile = perXcd ? (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3) : blockIdx.x;
   const uint32_t l = tile * (TILE / L) + threadIdx.x / L;  // all L lanes of a group share the bot
   const uint32_t sub = threadIdx.x % L;
+#ifdef PB_TIMELINE
+  // (stored at once: a start stamp kept in registers to the end cost the kernel a wave per SIMD)
+  if (pbTimelineBuf && threadIdx.x == 0)
+    pbTimelineBuf[4ull * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (l >= n) return;
   const uint32_t s = blockIdx.y * n + l;  // global slot; the cell table holds global slots too
   const uint32_t *__restrict__ cellS = cellSAll + (size_t)blockIdx.y * (P.numCells + 1u);
@@ -533,6 +546,14 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
     absA[s] = F.fa;
     absR[s] = F.fr;
   }
+#ifdef PB_TIMELINE
+  if (pbTimelineBuf && threadIdx.x == 0) {
+    unsigned long long *row = pbTimelineBuf + 4ull * (blockIdx.y * gridDim.x + blockIdx.x);
+    row[1] = __builtin_amdgcn_s_memrealtime();
+    row[2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, bits 0..3
+    row[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID (wave/simd/cu/sh/se)
+  }
+#endif
 }
 
 // Streamlined force kernel (force variant 3): same inputs, outputs and fusion as k_force, pair
@@ -827,10 +848,12 @@ __global__ __launch_bounds__(TILE) void k_cell_scan(const uint32_t *__restrict__
 
 // min over a simulation's bots of the squared distance to the light, as the host loop of
 // particlebot.cpp:215-228 squares it: powf(light-x,2)+powf(light-y,2).  Non-negative floats order
-// like their bit patterns, so an integer atomicMin is exact and order-independent.
+// like their bit patterns, so an integer min is exact and order-independent.  Two levels: one value
+// per workgroup (wave shuffles, then LDS), then one wave per simulation over those (k_min_final) --
+// thousands of atomicMin on one address took 46 us at 10^6 bots, this takes ~10.
 __global__ __launch_bounds__(TILE) void k_min_dist2(const PbDevParams *__restrict__ params,
                                                     const float4 *__restrict__ pr, uint32_t n,
-                                                    uint32_t *__restrict__ outBits) {
+                                                    uint32_t *__restrict__ partial) {
   const PbDevParams &P = params[blockIdx.y];
   const uint32_t l = blockIdx.x * TILE + threadIdx.x;
   uint32_t bits = 0x7f800000u;  // +inf
@@ -851,8 +874,23 @@ __global__ __launch_bounds__(TILE) void k_min_dist2(const PbDevParams *__restric
     uint32_t m = waveMin[0];
 #pragma unroll
     for (int w = 1; w < TILE / 64; w++) m = waveMin[w] < m ? waveMin[w] : m;
-    atomicMin(&outBits[blockIdx.y], m);  // one per workgroup
+    partial[blockIdx.y * gridDim.x + blockIdx.x] = m;
   }
+}
+
+__global__ __launch_bounds__(64) void k_min_final(const uint32_t *__restrict__ partial, uint32_t nb,
+                                                  uint32_t *__restrict__ outBits) {
+  uint32_t bits = 0x7f800000u;
+  for (uint32_t b = threadIdx.x; b < nb; b += 64u) {
+    const uint32_t o = partial[blockIdx.x * nb + b];
+    bits = o < bits ? o : bits;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(bits, d, 64);
+    bits = o < bits ? o : bits;
+  }
+  if (threadIdx.x == 0) outBits[blockIdx.x] = bits;
 }
 
 // updatePhase (impl.cuh:264-290) + add_normal_noise (impl.cuh:43-51) in slot order.  rng: per-bot
@@ -1145,6 +1183,7 @@ struct pbSim {
   int variant = 2;  // force kernel: 0 reference-shaped branches, 1 branch-free, 2 (default) + fast exact math
   int resident = 0;     // 0 automatic, 1 never, 2 whenever the simulation fits one workgroup (n <= 1024)
   int lanesPerBot = 0;  // lanes per bot of the per-step force kernel: 0 automatic; 1 (throughput form), 2, 4, 8, 16
+  unsigned debugLdsBytes = 0;  // PB_DEBUG_LDS_BYTES under PB_ALLOW_ENV_OVERRIDES=1 (tools/occupancy_sweep.py --lds)
   int rng = 0;          // phase noise: 0 PB-RNG v1 (counter based), 1 cuRAND-compatible XORWOW (pb_xorwow.hpp)
   pbSimStats stats{};
 };
@@ -1164,7 +1203,8 @@ void launchForceT(pbSim *S, int c, int o, float dt, float tNext, int doRadiusNex
   // XCD-aware order only pays when a simulation spans many tiles
   const uint32_t perXcd = (L == 1 && tiles >= 64u) ? cdiv(tiles, 8u) : 0u;
   const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
-  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK, L, NB>), grid, dim3(TILE), 0, S->stream, S->dP, S->pr[c],
+  // (debugLdsBytes: an occupancy experiment -- unused dynamic LDS that only limits workgroups per CU)
+  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK, L, NB>), grid, dim3(TILE), S->debugLdsBytes, S->stream, S->dP, S->pr[c],
                      S->vel[c], S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c],
                      S->cellS, S->n, dt, tNext, doRadiusNext, perXcd);
 }
@@ -1325,8 +1365,10 @@ int phaseUpdate(pbSim *S) {
   const uint32_t n = S->n;
   const int c = S->cur;
   const dim3 g = gridOf(S), b(TILE);
-  PB_TRY(hipMemsetAsync(S->dMin, 0xff, sizeof(uint32_t) * S->nsims, S->stream));
-  hipLaunchKernelGGL(k_min_dist2, g, b, 0, S->stream, S->dP, S->pr[c], n, S->dMin);
+  // (the per-workgroup minima borrow the centroid reduction's scratch: 16 bytes per workgroup there)
+  uint32_t *partial = (uint32_t *)S->comPartial;
+  hipLaunchKernelGGL(k_min_dist2, g, b, 0, S->stream, S->dP, S->pr[c], n, partial);
+  hipLaunchKernelGGL(k_min_final, dim3(S->nsims), dim3(64), 0, S->stream, partial, cdiv(n, TILE), S->dMin);
   PB_TRY(hipMemcpyAsync(S->hMin, S->dMin, sizeof(uint32_t) * S->nsims, hipMemcpyDeviceToHost, S->stream));
   PB_TRY(hipStreamSynchronize(S->stream));
   for (uint32_t k = 0; k < S->nsims; k++) {
@@ -1534,6 +1576,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     if (const char *v = getenv("PB_FORCE_VARIANT")) rc |= pbSimSetForceVariant(S, atoi(v));
     if (const char *v = getenv("PB_LANES_PER_BOT")) rc |= pbSimSetLanesPerBot(S, atoi(v));
     if (const char *v = getenv("PB_RESIDENT")) rc |= pbSimSetResident(S, atoi(v));
+    if (const char *v = getenv("PB_DEBUG_LDS_BYTES")) S->debugLdsBytes = (unsigned)std::min(atol(v), 65536L);
     if (rc != PB_OK) {
       g_lastError = "pbSimCreateBatch: PB_FORCE_VARIANT / PB_LANES_PER_BOT / PB_RESIDENT out of range";
       delete S;
@@ -1951,6 +1994,12 @@ int pbClockSampleEnd(pbClockSample *h, double *mhz, double *seconds_sampled) {
   if (seconds_sampled) *seconds_sampled = (double)v[1] * 1e-8;
   return PB_OK;
 }
+
+#ifdef PB_TIMELINE
+int pbDebugSetTimeline(unsigned long long *deviceBuffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(pbTimelineBuf), &deviceBuffer, sizeof deviceBuffer) == hipSuccess ? PB_OK : PB_ERR_HIP;
+}
+#endif
 
 int pbSimSetResortEveryStep(pbSim *S, int on) {
   if (!S) return PB_ERR_ARG;

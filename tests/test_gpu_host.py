@@ -310,3 +310,76 @@ def test_cxx_rccl_ensemble_runner_equals_python_layer(tmp_path):
     rows, steps = ensemble.run_local(cfg, over, {"max_time": "1.55", "dump_interval": "0.5"})
     assert steps == info["steps_per_member"]
     assert np.array_equal(got, rows)
+
+
+def _render_expected(P, pos, rad, dead, size, cx, cy, half, light_radius=0.25):
+    """Independent numpy rasteriser of the headless frame (stand-in for display() +
+    updateCol_k, particlebot_kernel_impl.cuh:401-443), painter's order: rectangles, circles, light,
+    bots by index; float32 arithmetic as in Particlebot::writeFramePPM."""
+    f = np.float32
+    img = np.full((size, size, 3), 245, np.uint8)
+    scale = f(0.5) * f(size) / f(half)
+    px = lambda x: f(0.5) * f(size) - (f(x) - f(cx)) * scale
+    py = lambda y: f(0.5) * f(size) - (f(y) - f(cy)) * scale
+    yy, xx = np.mgrid[0:size, 0:size]
+    xc, yc = xx.astype(f) + f(0.5), yy.astype(f) + f(0.5)
+
+    def disc(x, y, r, col):
+        ax, ay, pr = px(x), py(y), f(r) * scale
+        x0, x1 = max(0, int(np.floor(ax - pr))), min(size - 1, int(np.ceil(ax + pr)))
+        y0, y1 = max(0, int(np.floor(ay - pr))), min(size - 1, int(np.ceil(ay + pr)))
+        if x0 > x1 or y0 > y1:
+            return
+        dx, dy = xc[y0:y1 + 1, x0:x1 + 1] - ax, yc[y0:y1 + 1, x0:x1 + 1] - ay
+        m = (dx * dx + dy * dy) <= pr * pr
+        img[y0:y1 + 1, x0:x1 + 1][m] = col
+
+    for k in range(P.nobstacles):
+        xa, xb = px(P.x2obs[k]), px(P.x1obs[k])
+        ya, yb = py(P.y2obs[k]), py(P.y1obs[k])
+        img[max(0, int(np.floor(ya))):min(size - 1, int(np.ceil(yb))) + 1,
+            max(0, int(np.floor(xa))):min(size - 1, int(np.ceil(xb))) + 1] = 110
+    for k in range(P.n_cir_obstacles):
+        disc(P.x_cir_obs[k], P.y_cir_obs[k], P.r_cir_obs[k], (110, 110, 110))
+    disc(P.light_x, P.light_y, light_radius, (250, 210, 40))
+    span = f(P.max_radius) - f(P.min_radius)
+    for i in range(len(rad)):
+        r = f(rad[i])
+        col = (0, 0, 0)
+        if not dead[i]:
+            g = (f(P.max_radius) - r) / span
+            b = (r - f(P.min_radius)) / span
+            G = min(f(255), max(f(0), f(20) + f(180) * g * g))
+            B = min(f(255), max(f(0), f(30) + f(180) * np.sqrt(max(f(0), b), dtype=f)))
+            col = (30, int(G), int(B))
+        disc(pos[i, 0], pos[i, 1], r, col)
+    return img
+
+
+@pytest.mark.parametrize("cfg,steps", [("example_dead_cells.cfg", 150), ("example_obstacle.cfg", 260),
+                                       ("example_gap.cfg", 120)])
+def test_headless_frame_of_gpu_state_equals_render_of_oracle_state(host, orc, tmp_path, cfg, steps):
+    """the frame the product writes from the fused engine's state after `steps`
+    timesteps (radii mid-actuation, dead bots, circle / rectangle obstacles, the light) is, pixel for
+    pixel, what an independent rasteriser draws from the ORACLE's state at the same step."""
+    over = dict(max_time="1e9")
+    sim = host.HostSim(EX(cfg), **over)
+    sim.advance(steps)
+    path = str(tmp_path / "f.ppm")
+    size, half, cam_x = 500, 6.5, 2.0   # blob around (5, 0), light at x = -2 ... -5, obstacles between
+    c = host.load_config(EX(cfg))
+    sim.write_frame(path, size=size, center=(cam_x, 0.0), half_extent=half)
+    raw = open(path, "rb").read()
+    header = f"P6\n{size} {size}\n255\n".encode()
+    got = np.frombuffer(raw[len(header):], np.uint8).reshape(size, size, 3)
+    P = orc.load_cfg(EX(cfg), max_time=1e9)
+    osim = orc.Sim(P)
+    osim.run(steps)
+    assert_bit_equal(sim.get("pos"), osim.get("pos"), "state the frame is drawn from")
+    want = _render_expected(P, osim.get("pos"), osim.get("rad"), osim.get("dead"), size, cam_x, 0.0, half,
+                            light_radius=c.light_radius)
+    assert np.array_equal(got, want), int((got != want).any(axis=2).sum())
+    # the frame shows what it should: bots of several radii (several blues), grey obstacles if any
+    assert len({tuple(p) for p in got.reshape(-1, 3)[::7]}) > 5
+    if c.nobstacles or c.n_cir_obstacles:
+        assert ((got == 110).all(axis=2)).sum() > 50

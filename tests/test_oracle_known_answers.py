@@ -125,3 +125,20 @@ def test_wall_clamp_and_hash_wrap_and_sort(orc):
     vals = np.arange(6, dtype=np.uint32)
     orc.lib().orc_sortParticlebots(keys, vals, 6)
     assert list(keys) == [0, 1, 1, 5, 5, 5] and list(vals) == [3, 1, 4, 0, 2, 5]
+
+
+def test_zero_Nx_falls_back_to_the_placement_size(orc):
+    """particlebot.cpp:772-773: `if(!params.Nx) params.Nx = particlebotConfigSize.x` -- ceil(sqrt(n))
+    after CONFIG_RANDOM (:624), 2 * rings after the hexagonal placement (:479).  Unreachable from a
+    .cfg (the key `Nx` is too short to be read), reachable through SimParams."""
+    P = orc.default_params(nCells=50, nDead=0, seed=3, phase_std=0.0, max_time=1e9, Nx=0)
+    s = orc.Sim(P)                      # reset() inside
+    P2 = orc.default_params(nCells=50, nDead=0, seed=3, phase_std=0.0, max_time=1e9, Nx=8)
+    s2 = orc.Sim(P2)
+    s.run(30)
+    s2.run(30)
+    assert np.array_equal(s.get("rad"), s2.get("rad"))      # ceil(sqrt(50)) = 8: same actuation period
+    P3 = orc.default_params(nCells=50, nDead=0, seed=3, phase_std=0.0, max_time=1e9, Nx=5)
+    s3 = orc.Sim(P3)
+    s3.run(30)
+    assert not np.array_equal(s.get("rad"), s3.get("rad"))

@@ -26,3 +26,16 @@ tools/valu_rate > "$OUT/valu_rate.txt" 2>&1
 python3 bench.py $ARGS 2>/dev/null | tail -1 > "$OUT/bench_unprofiled.json"
 python3 tools/summarize_profile.py "$OUT" "$OUT/traffic.json" > "$OUT/summary.md" 2>"$OUT/summarize.err"
 cat "$OUT/summary.md"
+# SURVEY 8(d) caveat 2: the same kernel at 8 x 10^6 bots (544 MB of state, beyond the 256 MiB Infinity
+# Cache): kernel trace + the two HBM-traffic passes, summarised next to the 10^6-bot profile
+if [ "${PB_PROFILE_LARGE:-1}" = "1" ]; then
+  OUT=gpurun_out/prof_${TAG}_8m
+  mkdir -p "$OUT"
+  ARGS="--bots 8000000 --steps 60 --warmup 20 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob"
+  run trace --kernel-trace --stats
+  run pmc_fetch --pmc FETCH_SIZE
+  run pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+  python3 bench.py $ARGS 2>/dev/null | tail -1 > "$OUT/bench_unprofiled.json"
+  python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
+  cat "$OUT/summary.md"
+fi
