@@ -370,6 +370,9 @@ def run_ensemble_workload(args, rank, world, dist, torch):
         done = [0] * len(ens)
 
         def one(i):
+            if torch is not None and i > 0:
+                # HIP's current device is per host thread: a new thread starts on device 0
+                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
             done[i] = ens[i].run_steps(nsteps)
         th = [threading.Thread(target=one, args=(i,)) for i in range(1, len(ens))]
         for t in th:

@@ -1148,6 +1148,7 @@ struct pbSim {
   PbDevParams *dP = nullptr;
   SimParams host;  // schedule-relevant fields (shared by the batch): max_time, phase_update_interval, control
   uint32_t nsims = 1, n = 0, total = 0;
+  int device = 0;  // the device the batch lives on; every entry point makes it the calling thread's current one
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -1196,6 +1197,10 @@ inline bool gate(float t, float interval, float dt) {
 }
 
 inline dim3 gridOf(const pbSim *S) { return dim3(cdiv(S->n, TILE), S->nsims); }
+
+// HIP's current device is per host thread (a new thread starts on device 0): a caller that drives
+// several batches from several threads must not have to remember that
+inline void useDevice(const pbSim *S) { (void)hipSetDevice(S->device); }
 
 template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB>
 void launchForceT(pbSim *S, int c, int o, float dt, float tNext, int doRadiusNext) {
@@ -1482,6 +1487,7 @@ const char *pbGetLastErrorString(void) { return g_lastError.c_str(); }
 
 void pbSimDestroy(pbSim *S) {
   if (!S) return;
+  useDevice(S);
   if (S->stream) (void)hipStreamSynchronize(S->stream);
   for (int i = 0; i < 2; i++) {
     (void)hipFree(S->pr[i]);
@@ -1556,6 +1562,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     return PB_ERR_NO_DEVICE;
   }
   pbSim *S = new pbSim();
+  (void)hipGetDevice(&S->device);
   S->host = params[0];
   S->host.x1obs = S->host.x2obs = S->host.y1obs = S->host.y2obs = nullptr;
   S->host.x_cir_obs = S->host.y_cir_obs = S->host.r_cir_obs = nullptr;
@@ -1655,6 +1662,7 @@ int pbSimBatchSize(pbSim *S, unsigned *nsims, unsigned *nbots) {
 int pbSimSetStateRangeOf(pbSim *S, unsigned sim, unsigned start, unsigned count, const float *pos,
                          const float *vel, const float *rad, const float *phase, const int *dead) {
   if (!S || sim >= S->nsims) return PB_ERR_ARG;
+  useDevice(S);
   if (start > S->n || count > S->n - start) {
     g_lastError = "pbSimSetStateRangeOf: [start, start + count) must lie inside the simulation's bots";
     return PB_ERR_ARG;
@@ -1693,6 +1701,7 @@ int pbSimSetState(pbSim *S, const float *pos, const float *vel, const float *rad
 int pbSimGetStateOf(pbSim *S, unsigned sim, float *pos, float *vel, float *rad, float *phase, int *dead,
                     float *absForce_a, float *absForce_r) {
   if (!S || sim >= S->nsims) return PB_ERR_ARG;
+  useDevice(S);
   const size_t n = S->n;
   char *st = S->stage;
   const int rc = gatherToStage(S, sim);
@@ -1716,6 +1725,7 @@ int pbSimGetState(pbSim *S, float *pos, float *vel, float *rad, float *phase, in
 /* ---- layout (which bot sits in which slot, and under which stale cell) for exact checkpoints ---- */
 int pbSimGetLayoutOf(pbSim *S, unsigned sim, unsigned *orig, unsigned *keys, int *sorted) {
   if (!S || sim >= S->nsims) return PB_ERR_ARG;
+  useDevice(S);
   const size_t n = S->n;
   if (sorted) *sorted = S->haveCells ? 1 : 0;
   PB_TRY(hipStreamSynchronize(S->stream));
@@ -1733,6 +1743,7 @@ int pbSimGetLayoutOf(pbSim *S, unsigned sim, unsigned *orig, unsigned *keys, int
 
 int pbSimSetLayoutOf(pbSim *S, unsigned sim, const unsigned *orig, const unsigned *keys) {
   if (!S || sim >= S->nsims || !orig || !keys) return PB_ERR_ARG;
+  useDevice(S);
   const size_t n = S->n;
   if (S->layoutOrig.empty()) {
     S->layoutOrig.assign((size_t)S->total, 0);
@@ -1771,6 +1782,7 @@ int pbSimSetLayoutOf(pbSim *S, unsigned sim, const unsigned *orig, const unsigne
 
 int pbSimSetForcesOf(pbSim *S, unsigned sim, const float *absForce_a, const float *absForce_r) {
   if (!S || sim >= S->nsims || !absForce_a || !absForce_r) return PB_ERR_ARG;
+  useDevice(S);
   const size_t n = S->n;
   float *dA = (float *)(S->stage + 28 * n), *dR = (float *)(S->stage + 32 * n);
   PB_TRY(hipMemcpyAsync(dA, absForce_a, 4 * n, hipMemcpyHostToDevice, S->stream));
@@ -1817,6 +1829,7 @@ int rngInit(pbSim *S, unsigned draws) {
 
 int pbSimSetPhaseDraws(pbSim *S, unsigned draws) {
   if (!S) return PB_ERR_ARG;
+  useDevice(S);
   S->phaseDraws = draws;
   if (S->rng != PB_RNG_COUNTER) return rngInit(S, draws);  // the states are a function of (seed, bot, draws)
   return PB_OK;
@@ -1827,6 +1840,7 @@ int pbSimSetRng(pbSim *S, int kind) {
     g_lastError = "pbSimSetRng: kind must be PB_RNG_COUNTER, PB_RNG_XORWOW_CURAND or PB_RNG_XORWOW_ROCRAND";
     return PB_ERR_ARG;
   }
+  useDevice(S);
   S->rng = kind;
   S->phaseDraws = 0;
   if (kind == PB_RNG_COUNTER) return PB_OK;
@@ -1835,6 +1849,7 @@ int pbSimSetRng(pbSim *S, int kind) {
 
 int pbSimGetRngStatesOf(pbSim *S, unsigned sim, pbRngState *states) {
   if (!S || sim >= S->nsims || !states || S->rng == PB_RNG_COUNTER || !S->rngState) return PB_ERR_ARG;
+  useDevice(S);
   PB_TRY(hipStreamSynchronize(S->stream));
   PB_TRY(hipMemcpy(states, S->rngState + (size_t)sim * S->n, sizeof(pbRngState) * (size_t)S->n, hipMemcpyDeviceToHost));
   return PB_OK;
@@ -1842,6 +1857,7 @@ int pbSimGetRngStatesOf(pbSim *S, unsigned sim, pbRngState *states) {
 
 int pbSimStep(pbSim *S, float deltaTime, float sort_interval, int nsteps, int *steps_done) {
   if (!S || nsteps < 0) return PB_ERR_ARG;
+  useDevice(S);
   if (steps_done) *steps_done = 0;
   return stepMany(S, deltaTime, sort_interval, nsteps, steps_done);
 }
@@ -1849,6 +1865,7 @@ int pbSimStep(pbSim *S, float deltaTime, float sort_interval, int nsteps, int *s
 int pbSimStepTimed(pbSim *S, float deltaTime, float sort_interval, int nsteps, int *steps_done,
                    float *elapsed_ms) {
   if (!S || nsteps < 0) return PB_ERR_ARG;
+  useDevice(S);
   if (steps_done) *steps_done = 0;
   PB_TRY(hipEventRecord(S->ev0, S->stream));
   const int rc = stepMany(S, deltaTime, sort_interval, nsteps, steps_done);
@@ -1863,12 +1880,14 @@ int pbSimStepTimed(pbSim *S, float deltaTime, float sort_interval, int nsteps, i
 
 int pbSimSynchronize(pbSim *S) {
   if (!S) return PB_ERR_ARG;
+  useDevice(S);
   PB_TRY(hipStreamSynchronize(S->stream));
   return PB_OK;
 }
 
 int pbSimCentroids(pbSim *S, double *cxcy) {
   if (!S || !cxcy) return PB_ERR_ARG;
+  useDevice(S);
   const uint32_t nb = cdiv(S->n, TILE);
   const int c = S->cur;
   hipLaunchKernelGGL(k_com_scatter, gridOf(S), dim3(TILE), 0, S->stream, S->orig[c], S->pr[c], S->comPos, S->n);

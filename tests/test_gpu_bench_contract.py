@@ -75,3 +75,21 @@ def test_ensemble5_workload_line():
                "--no-cpu-baseline")
     assert d["config"]["bots_per_member"] == [100000] and d["config"]["members_per_gpu"] == 2
     assert d["value"] > 1e8 and d["summary_rows_gathered"] == [[2, 2, 4]]
+
+
+def test_arena_line_through_rccl_with_one_rank_and_gpus_flag_is_checked():
+    """The N > 1 code path of the default workload on one GPU: --force-dist initialises RCCL (world 1),
+    runs the barrier / max-over-ranks all_reduce / all_gather of the arena summaries.  And `--gpus 2`
+    without a launcher on a one-GPU box refuses loudly instead of silently running one arena."""
+    d = _bench("--bots", "150000", "--steps", "40", "--warmup", "10", "--force-dist", "--no-cpu-baseline",
+               "--no-survey-literal", "--no-streamlined", "--no-large-arena", "--no-blob")
+    assert d["n_gpus"] == 1 and len(d["summaries_time_comx_comy"]) == 1 and d["value"] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"],
+                             capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert out.returncode == 2 and "only" in out.stderr and "GPU" in out.stderr
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5"],
+                         capture_output=True, text=True, timeout=60, cwd=ROOT,
+                         env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr
