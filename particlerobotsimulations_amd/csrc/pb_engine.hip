@@ -78,6 +78,21 @@ constexpr int TILE = PB_TILE;
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+#ifdef PB_TIMELINE
+// Diagnostic build only (-DPB_TIMELINE, tools/timeline.py): every workgroup of k_force stamps the
+// 100 MHz real-time counter when it starts, when its first wave reaches its first neighbour pair, when
+// that wave is half way through its stencil and when the workgroup ends, with the XCD and CU it ran
+// on, into a buffer (8 words per workgroup) set by pbDebugSetTimeline.  Never in the shipped library.
+__device__ unsigned long long *pbTimelineBuf = nullptr;
+#define PB_TL_STAMP(word)                                                                              \
+  do {                                                                                                 \
+    if (pbTimelineBuf && threadIdx.x == 0)                                                             \
+      pbTimelineBuf[8ull * (blockIdx.y * gridDim.x + blockIdx.x) + (word)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define PB_TL_STAMP(word) do { } while (0)
+#endif
+
 // ---- kernels ------------------------------------------------------------------------------
 
 // stand-alone radius actuation + integration for one step (impl.cuh:124-181 + :53-103), in place
@@ -314,8 +329,10 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
     bounds(stride, loB, hiB);
     float4 qA = at(loA);
     float2 vA = vat(loA);
+    PB_TL_STAMP(4);
 #pragma unroll 1
     for (int si = 0; si < 10; si += stride) {
+      if (si == 4) PB_TL_STAMP(5);
       const uint32_t lo = loA, end = hiA;
       float4 q0 = qA;
       float2 v0 = vA;
@@ -478,13 +495,6 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
   pbSweepC<PAYLOAD, FLAT, FAST, L, NB, false>(P, prIn, velIn, cellS, base, s, sub, me, v, att1, F, none);
 }
 
-#ifdef PB_TIMELINE
-// Diagnostic build only (-DPB_TIMELINE, tools/timeline.py): every workgroup of k_force stamps the
-// 100 MHz real-time counter when it starts and when it ends, with the XCD and CU it ran on, into a
-// buffer set by pbDebugSetTimeline.  Never compiled into the shipped library.
-__device__ unsigned long long *pbTimelineBuf = nullptr;
-#endif
-
 // Forces + kick of step n (impl.cuh:657-831); with FUSE also radius + integration of step n+1.
 // PAYLOAD: object-transport mode (nDead == -1), per-pair attraction factors.  FLAT: branch-free
 // pair evaluation instead of the reference-shaped branches (pbPair).
@@ -508,8 +518,7 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
   const uint32_t sub = threadIdx.x % L;
 #ifdef PB_TIMELINE
   // (stored at once: a start stamp kept in registers to the end cost the kernel a wave per SIMD)
-  if (pbTimelineBuf && threadIdx.x == 0)
-    pbTimelineBuf[4ull * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memrealtime();
+  PB_TL_STAMP(0);
 #endif
   if (l >= n) return;
   const uint32_t s = blockIdx.y * n + l;  // global slot; the cell table holds global slots too
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
   }
 #ifdef PB_TIMELINE
   if (pbTimelineBuf && threadIdx.x == 0) {
-    unsigned long long *row = pbTimelineBuf + 4ull * (blockIdx.y * gridDim.x + blockIdx.x);
+    unsigned long long *row = pbTimelineBuf + 8ull * (blockIdx.y * gridDim.x + blockIdx.x);
     row[1] = __builtin_amdgcn_s_memrealtime();
     row[2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, bits 0..3
     row[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID (wave/simd/cu/sh/se)

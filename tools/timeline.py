@@ -31,9 +31,10 @@ def main():
     sim = bench.make_sim(pb, n, bench.LATTICE_PITCH, seed=1)
     sim.set_lanes_per_bot(1)
     sim.step(200)
+    sim.synchronize()  # (the pointer below must not change under running kernels)
     tiles = (n + 255) // 256
     grid = ((tiles + 7) // 8) * 8 if tiles >= 64 else tiles
-    buf = pb.DeviceArray((grid, 4), np.uint64, fill=0)
+    buf = pb.DeviceArray((grid + 64, 8), np.uint64, fill=0)  # (+64 rows of slack)
     L = _capi.lib()
     L.pbDebugSetTimeline.argtypes = [C.c_void_p]
     assert L.pbDebugSetTimeline(buf.ptr) == 0
@@ -41,6 +42,8 @@ def main():
     sim.synchronize()
     L.pbDebugSetTimeline(None)
     t = buf.download()
+    print("rows written beyond the grid:", int((t[grid:] != 0).any(axis=1).sum()))
+    t = t[:grid]
     t = t[t[:, 1] > 0]
     t0 = t[:, 0].min()
     start = (t[:, 0] - t0) * 0.01  # us
@@ -62,6 +65,15 @@ def main():
     print("lifetime by start-time decile (us):", [round(float(life[order[i::10]].mean()), 1) for i in range(10)][:1],
           [round(float(np.mean(life[(start >= lo) & (start < lo + 10)])), 1) if ((start >= lo) & (start < lo + 10)).any() else None
            for lo in range(0, int(end.max()), 10)])
+    first_pair = (t[:, 4] - t0) * 0.01 - start   # start -> first neighbour pair (the dependent load chain)
+    half = (t[:, 5] - t0) * 0.01 - start         # start -> half way through the stencil
+    r1 = start < 2.0
+    r2 = start > 20.0
+    for name, m in (("first round (started < 2 us)", r1), ("later rounds (started > 20 us)", r2)):
+        if m.any():
+            print(f"{name}: start->first pair p10/p50/p90 {np.percentile(first_pair[m], [10, 50, 90]).round(1).tolist()} us; "
+                  f"start->half way {np.percentile(half[m], [10, 50, 90]).round(1).tolist()}; "
+                  f"lifetime {np.percentile(life[m], [10, 50, 90]).round(1).tolist()}")
     print("workgroups per XCD:", np.bincount(xcc, minlength=8).tolist())
     per_cu = np.bincount(cuid)
     per_cu = per_cu[per_cu > 0]
