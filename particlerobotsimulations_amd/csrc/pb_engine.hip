@@ -651,6 +651,7 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
     }
   };
 
+#if PB_STREAM_PAIRS
   // the same for two candidates (slots off and off + 16 bytes) side by side
   auto two = [&](const float4 &qa, const float4 &qb, uint32_t off) __attribute__((always_inline)) {
     const float rxa = qa.x - me.x, rya = qa.y - me.y, rxb = qb.x - me.x, ryb = qb.y - me.y;
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
       }
     }
   };
+#endif
 
   const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
   const uint32_t GX = P.gridX;
