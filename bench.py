@@ -200,8 +200,12 @@ def streamlined_leg(pb, n, pitch, steps, warmup):
             "ms_per_step": ms / max(done, 1), "finite_at_end": bool(cx == cx and cy == cy),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "kernel": "k_force_stream<FUSE>"},
-            "parity": {"against": f"the exact kernel (bit-identical to the oracle) from the same state after "
-                                  f"{warmup} steps", "window_steps": 10, "max_abs_dpos": float(d.max()),
+            "parity": {"against": f"the exact kernel from the same state after {warmup} steps; the exact kernel is "
+                                  "bit-identical to the CPU oracle on this very workload "
+                                  "(tests/test_gpu_baseline_configs.py::test_bench_headline_workload_matches_oracle), so "
+                                  "these are also the deviations from the oracle; oracle-side flip statistics on "
+                                  "blobs: tests/test_gpu_streamlined.py (bench.py may use oracle/ only in cpu_baseline)",
+                       "window_steps": 10, "max_abs_dpos": float(d.max()),
                        "median_abs_dpos": float(np.median(d)), "bots_beyond_1e-5_relative": int((rel > 1e-5).sum()),
                        "com_abs_dev": com},
             "note": "opt-in: pbSimSetForceVariant(sim, 3).  v_rsq/v_rcp/FMA arithmetic, |F_attr| taken from its "

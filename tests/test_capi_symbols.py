@@ -93,3 +93,33 @@ def test_engine_error_paths_without_a_gpu(capi):
     assert L.pbSimStep(None, C.c_float(0.01), C.c_float(180.0), 1, None) == 2
     assert L.pbSimSetForceVariant(None, 2) == 2 and L.pbSimSetLanesPerBot(None, 8) == 2
     assert L.pbSimSetResident(None, 0) == 2 and L.pbSimGetTime(None, None) == 2
+
+
+def test_ensemble_header_symbols_are_exported_by_the_host_library():
+    """include/particlebot_ensemble.h (the multi-GPU ensemble layer's C-ABI) against
+    libparticlebot_host.so: every declared function is exported, and the two pure helpers behave."""
+    import ctypes as C
+
+    from particlerobotsimulations_amd import host
+    text = open(os.path.join(ROOT, "include", "particlebot_ensemble.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = {m.group(1) for m in re.finditer(r"\b(pbEnsemble\w+)\s*\(", text)}
+    assert names == {"pbEnsembleCreate", "pbEnsembleDestroy", "pbEnsembleRun", "pbEnsembleRunSteps",
+                     "pbEnsembleSynchronize", "pbEnsembleGetState", "pbEnsembleNumBots", "pbEnsembleShard",
+                     "pbEnsembleAssemble"}
+    L = host.lib()
+    for n in names:
+        assert hasattr(L, n), n
+    L.pbEnsembleShard.argtypes = [C.c_int, C.c_int, C.c_int]
+    assert [L.pbEnsembleShard(10, r, 4) for r in range(4)] == [3, 3, 2, 2]
+    assert L.pbEnsembleShard(10, 4, 4) == 0 and L.pbEnsembleShard(-1, 0, 4) == 0
+    L.pbEnsembleAssemble.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.pbEnsembleAssemble(4, 2, 1, None, None) != 0   # null buffers are refused
+    # without a GPU a valid ensemble request fails cleanly (NULL), never falls back to the CPU
+    import torch
+    if not torch.cuda.is_available():
+        L.pbEnsembleCreate.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
+        L.pbEnsembleCreate.restype = C.c_void_p
+        arr = (C.c_char_p * 1)(b"seed\n1")
+        cfg = os.path.join(ROOT, "examples", "example_dead_cells.cfg").encode()
+        assert L.pbEnsembleCreate(cfg, None, arr, 1) is None
