@@ -175,7 +175,11 @@ def main():
     sweep = (args.sweep[0], args.sweep[1:]) if args.sweep else None
     ids = shard(args.members, rank, world)
     t0 = time.perf_counter()
-    rows, steps = run_local(args.cfg, [member_overrides(k, args.seed0, sweep) for k in ids], dict(args.set))
+    e = LocalEnsemble(args.cfg, [member_overrides(k, args.seed0, sweep) for k in ids], dict(args.set))
+    placement_s = time.perf_counter() - t0  # host-side placement of this rank's members (all cores)
+    steps = e.run()
+    rows = e.rows
+    e.close()
     wall = time.perf_counter() - t0
     allrows = gather_summaries(rows, args.members, rank, world, dist, device)
     if world > 1:
@@ -192,6 +196,7 @@ def main():
         print(json.dumps({
             "cfg": os.path.basename(args.cfg), "members": args.members, "n_gpus": world, "bots_per_member": int(n),
             "steps_per_member": steps, "rows_per_member": int(allrows.shape[1]), "wall_s": wall,
+            "placement_s_rank0": placement_s, "placement_share_rank0": placement_s / wall,
             "sims_per_s": args.members / wall, "particle_steps_per_s": args.members * n * steps / wall,
             "progress_toward_light_mean": float(np.nanmean(toward)), "progress_toward_light_std": float(np.nanstd(toward)),
         }))
