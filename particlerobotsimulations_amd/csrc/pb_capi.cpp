@@ -358,7 +358,7 @@ void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const
   if (const char *v = getenv("PB_HOST_THREADS")) nthreads = (unsigned)atoi(v);
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof set, &set) == 0) nthreads = std::min<unsigned>(nthreads, (unsigned)CPU_COUNT(&set));
-  nthreads = std::max(1u, std::min<unsigned>(std::min(nthreads, 32u), (unsigned)nmembers));
+  nthreads = std::max(1u, std::min<unsigned>(std::min(nthreads, 128u), (unsigned)nmembers));
   std::vector<std::thread> pool;
   for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker);
   worker();
