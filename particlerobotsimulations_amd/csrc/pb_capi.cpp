@@ -355,6 +355,12 @@ void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const
     }
   };
   unsigned nthreads = std::thread::hardware_concurrency();
+  // one process per GPU: share the host's cores between the ranks of this node
+  for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE"})
+    if (const char *v = getenv(name)) {
+      if (atoi(v) > 1) nthreads = std::max(1u, nthreads / (unsigned)atoi(v));
+      break;
+    }
   if (const char *v = getenv("PB_HOST_THREADS")) nthreads = (unsigned)atoi(v);
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof set, &set) == 0) nthreads = std::min<unsigned>(nthreads, (unsigned)CPU_COUNT(&set));
