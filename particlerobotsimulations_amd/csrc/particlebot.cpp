@@ -822,7 +822,9 @@ void Particlebot::reset() {
 // ---- exact checkpoints (extension) -----------------------------------------
 
 namespace {
-const char kCkptMagic[8] = {'P', 'B', 'C', 'K', 'P', 'T', '1', 0};
+// '2': the phase-noise generator kind follows the draw counter ('1' files had the counter generator only)
+const char kCkptMagic[8] = {'P', 'B', 'C', 'K', 'P', 'T', '2', 0};
+const char kCkptMagicV1[8] = {'P', 'B', 'C', 'K', 'P', 'T', '1', 0};
 template <class T>
 bool putv(FILE *fp, const T *p, size_t count) { return fwrite(p, sizeof(T), count, fp) == count; }
 template <class T>
@@ -898,7 +900,8 @@ bool Particlebot::saveCheckpoint(FILE *fp) {
   if (pbSimGetPhaseDraws(sim, &draws) != PB_OK) return false;
   int rs[36];
   rng.getState(rs);
-  return putv(fp, kCkptMagic, 8) && putv(fp, &n, 1) && putv(fp, &time, 1) && putv(fp, &draws, 1) &&
+  const int kind = rngKindV;
+  return putv(fp, kCkptMagic, 8) && putv(fp, &n, 1) && putv(fp, &time, 1) && putv(fp, &draws, 1) && putv(fp, &kind, 1) &&
          putv(fp, &sorted, 1) && putv(fp, rs, 36) && putv(fp, hPos, 2 * (size_t)n) && putv(fp, hVel, 2 * (size_t)n) &&
          putv(fp, hRad, n) && putv(fp, hphase, n) && putv(fp, hDead, n) && putv(fp, absA.data(), n) &&
          putv(fp, absR.data(), n) && putv(fp, orig.data(), n) && putv(fp, keys.data(), n);
@@ -912,10 +915,13 @@ bool Particlebot::loadCheckpoint(FILE *fp) {
   float t = 0;
   unsigned draws = 0;
   int sorted = 0, rs[36];
-  if (!getv(fp, magic, 8) || memcmp(magic, kCkptMagic, 8) != 0 || !getv(fp, &fileN, 1) || fileN != n) return false;
+  if (!getv(fp, magic, 8)) return false;
+  const bool v1 = memcmp(magic, kCkptMagicV1, 8) == 0;
+  if ((!v1 && memcmp(magic, kCkptMagic, 8) != 0) || !getv(fp, &fileN, 1) || fileN != n) return false;
+  int kind = PB_RNG_COUNTER;
   std::vector<float> absA(n), absR(n);
   std::vector<unsigned> orig(n), keys(n);
-  if (!(getv(fp, &t, 1) && getv(fp, &draws, 1) && getv(fp, &sorted, 1) && getv(fp, rs, 36) &&
+  if (!(getv(fp, &t, 1) && getv(fp, &draws, 1) && (v1 || getv(fp, &kind, 1)) && getv(fp, &sorted, 1) && getv(fp, rs, 36) &&
         getv(fp, hPos, 2 * (size_t)n) && getv(fp, hVel, 2 * (size_t)n) && getv(fp, hRad, n) && getv(fp, hphase, n) &&
         getv(fp, hDead, n) && getv(fp, absA.data(), n) && getv(fp, absR.data(), n) && getv(fp, orig.data(), n) &&
         getv(fp, keys.data(), n)))
@@ -923,6 +929,9 @@ bool Particlebot::loadCheckpoint(FILE *fp) {
   if (sorted && pbSimSetLayoutOf(sim, 0, orig.data(), keys.data()) != PB_OK) return false;
   if (pbSimSetState(sim, hPos, hVel, hRad, hphase, hDead) != PB_OK) return false;
   if (pbSimSetForcesOf(sim, 0, absA.data(), absR.data()) != PB_OK) return false;
+  // the generator the run was using (its states are a function of seed, bot and draws made)
+  if (kind != PB_RNG_COUNTER && kind != PB_RNG_XORWOW_CURAND && kind != PB_RNG_XORWOW_ROCRAND) return false;
+  if (kind != rngKindV) setRng(kind);
   if (pbSimSetPhaseDraws(sim, draws) != PB_OK) return false;
   rng.setState(rs);
   setTime(t);

@@ -214,6 +214,26 @@ def test_ensemble_members_equal_individual_runs(host, tmp_path):
     assert len({tuple(np.round(r[-1, 1:3], 5)) for r in rows}) == len(seeds)
 
 
+def test_checkpoint_resume_with_xorwow_noise_restores_the_generator(host, tmp_path):
+    """A checkpoint of a `pb_rng curand` run records the generator kind; resuming into a simulation
+    created WITHOUT the key switches the generator and replays the draws: the resumed run is
+    bit-identical to the uninterrupted one across later phase updates (noise on)."""
+    ck = str(tmp_path / "xw.pbck")
+    over = dict(max_time="1e9", phase_update_interval="3")
+    a = host.HostSim(EX("example_dead_cells.cfg"), pb_rng="curand", **over)
+    a.advance(450)          # phase updates at t = 0 and 3: one Box-Muller pair consumed
+    a.save_checkpoint(ck)
+    a.advance(500)          # updates at 6 (fresh pair) and 9 (cached value)
+    b = host.HostSim(EX("example_dead_cells.cfg"), reset=False, **over)   # default generator
+    b.load_checkpoint(ck)
+    b.advance(500)
+    for k in ("pos", "vel", "rad", "phase"):
+        assert_bit_equal(a.get(k), b.get(k), k)
+    c = host.HostSim(EX("example_dead_cells.cfg"), **over)               # the default generator's run differs
+    c.advance(950)
+    assert not np.array_equal(c.get("phase"), a.get("phase"))
+
+
 def test_exact_checkpoint_resume(host, tmp_path):
     """saveCheckpoint/loadCheckpoint keep what the reference's CSV resume loses (phase,
     dead flags, noise-draw counter, the generator, contact forces and the STALE slot layout), so a
