@@ -535,6 +535,10 @@ void pbHostXorwowJumpMatrix(unsigned k, unsigned *rows) {
   memcpy(rows, hostJumpTable() + (size_t)(k & 31u) * PB_XW_MAT_WORDS, sizeof(uint32_t) * PB_XW_MAT_WORDS);
 }
 
+// the fused engine behind a HostSim (NULL for the other engines): lets a script reach pbSim* calls the
+// class does not wrap
+void *pbHostEngineHandle(void *hv) { return ((HostSim *)hv)->bot->engineHandle(); }
+
 unsigned pbHostNumBots(void *hv) { return ((HostSim *)hv)->bot->getParams().nCells; }
 
 }  // extern "C"
