@@ -214,6 +214,28 @@ def streamlined_leg(pb, n, pitch, steps, warmup):
                     "kernel."}
 
 
+def device_prewarm(pb, n, pitch, min_ms):
+    """The chip ramps its clocks over the first ~100 ms of load (measured: the first 20 steps after an
+    idle device run at 137 us, after 50 ms of the same kind of work at 115 us -- MI355X_MICROARCH.md
+    "DVFS give-back" asks for seconds of back-to-back launches before quoting a kernel).  A short timed
+    region (the driver's --steps 20 --warmup 5) would otherwise measure the ramp, not the kernel: step a
+    SCRATCH copy of the workload (its own simulation object, thrown away) for at least min_ms of device
+    time first.  The measured simulation still does its own W warm-up steps and exactly K timed ones."""
+    if min_ms <= 0:
+        return {"ms": 0.0, "steps": 0}
+    scratch = make_sim(pb, n, pitch, seed=12345)
+    scratch.step(5)
+    steps, ms = 0, 0.0
+    while ms < min_ms and steps < 20000:
+        d, m = scratch.step_timed(100)
+        steps += d
+        ms += m
+    scratch.close()
+    return {"ms": ms, "steps": steps,
+            "what": "a scratch copy of the workload stepped before the measured simulation is created, to bring "
+                    "the device out of its idle power state; not part of warmup/steps"}
+
+
 def profiled_traffic():
     """HBM bytes per k_force launch and its VALU instruction counts from the committed rocprofv3 PMC
     passes of this same command (profiles/latest_traffic.json, written by tools/profile.sh); None if
@@ -363,6 +385,8 @@ def run_ensemble_workload(args, rank, world, dist, torch):
 
     import numpy as np
     from particlerobotsimulations_amd import ensemble, host
+    import particlerobotsimulations_amd as pb
+    prewarm = device_prewarm(pb, 250_000, LATTICE_PITCH, args.prewarm_ms)
     batches = ensemble_batches(args.workload, rank, world, args.members_per_gpu)
     t_place = time.perf_counter()
     ens = [ensemble.LocalEnsemble(cfg, over, common) for cfg, common, over, _ in batches]
@@ -429,7 +453,7 @@ def run_ensemble_workload(args, rank, world, dist, torch):
                        "members_per_rank": [len(ensemble.shard(total_members, r, world)) * len(ens)
                                             for r in range(world)]},
             "sims_per_s": world * args.members_per_gpu * len(ens) / wall,
-            "placement_s": t_place,
+            "placement_s": t_place, "device_prewarm": prewarm,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_resident (<= 1024-bot members) / k_force (larger members)",
@@ -526,6 +550,8 @@ def main():
     ap.add_argument("--no-large-arena", action="store_true")
     ap.add_argument("--no-clock", action="store_true")
     ap.add_argument("--no-blob", action="store_true")
+    ap.add_argument("--prewarm-ms", type=float, default=100.0,
+                    help="device time of scratch work before the measured simulation (clock ramp); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the cpu_baseline sample")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path")
@@ -568,6 +594,7 @@ def main():
         return
 
     n = args.bots
+    prewarm = device_prewarm(pb, n, args.pitch, args.prewarm_ms)
     sim = make_sim(pb, n, args.pitch, seed=1 + rank)
     cfg = sim.config()
     assert cfg["force_variant"] == 2, cfg  # `value` is always the exact kernel
@@ -646,6 +673,7 @@ def main():
                                  "datasheet issue rate at the measured shader clock and at tools/valu_rate's rates; "
                                  "`traffic` (PMC) ~ algorithmic bytes, i.e. no wasted re-reads"},
             "device_ms_timed_region": dev_ms,
+            "device_prewarm": prewarm,
             "summaries_time_comx_comy": summaries,
         }
         sim.close()
