@@ -214,26 +214,34 @@ def streamlined_leg(pb, n, pitch, steps, warmup):
                     "kernel."}
 
 
-def device_prewarm(pb, n, pitch, min_ms):
-    """The chip ramps its clocks over the first ~100 ms of load (measured: the first 20 steps after an
-    idle device run at 137 us, after 50 ms of the same kind of work at 115 us -- MI355X_MICROARCH.md
-    "DVFS give-back" asks for seconds of back-to-back launches before quoting a kernel).  A short timed
-    region (the driver's --steps 20 --warmup 5) would otherwise measure the ramp, not the kernel: step a
-    SCRATCH copy of the workload (its own simulation object, thrown away) for at least min_ms of device
-    time first.  The measured simulation still does its own W warm-up steps and exactly K timed ones."""
-    if min_ms <= 0:
-        return {"ms": 0.0, "steps": 0}
-    scratch = make_sim(pb, n, pitch, seed=12345)
-    scratch.step(5)
-    steps, ms = 0, 0.0
-    while ms < min_ms and steps < 20000:
-        d, m = scratch.step_timed(100)
-        steps += d
-        ms += m
-    scratch.close()
-    return {"ms": ms, "steps": steps,
-            "what": "a scratch copy of the workload stepped before the measured simulation is created, to bring "
-                    "the device out of its idle power state; not part of warmup/steps"}
+class DevicePrewarm:
+    """The chip ramps its clocks over the first ~100 ms of load and drops them again when idle
+    (measured: the first 20 steps after an idle spell run at 137 us, after 50 ms of the same kind of
+    work at 115 us -- MI355X_MICROARCH.md "DVFS give-back" asks for seconds of back-to-back launches
+    before quoting a kernel).  A short timed region (the driver's --steps 20 --warmup 5) would otherwise
+    measure the ramp, not the kernel.  So a SCRATCH copy of the workload (its own simulation object,
+    thrown away) is created up front and stepped for at least min_ms of device time immediately before
+    the measured simulation's own W warm-up steps and exactly K timed ones."""
+
+    def __init__(self, pb, n, pitch, min_ms):
+        self.min_ms = min_ms
+        self.scratch = make_sim(pb, n, pitch, seed=12345) if min_ms > 0 else None
+        self.info = {"ms": 0.0, "steps": 0}
+
+    def run(self):
+        if self.scratch is None:
+            return self.info
+        steps, ms = 0, 0.0
+        while ms < self.min_ms and steps < 20000:
+            d, m = self.scratch.step_timed(100)
+            steps += d
+            ms += m
+        self.scratch.close()
+        self.scratch = None
+        self.info = {"ms": ms, "steps": steps,
+                     "what": "a scratch copy of the workload stepped right before the measured simulation's warm-up "
+                             "steps, to bring the device out of its idle power state; not part of warmup/steps"}
+        return self.info
 
 
 def profiled_traffic():
@@ -386,7 +394,7 @@ def run_ensemble_workload(args, rank, world, dist, torch):
     import numpy as np
     from particlerobotsimulations_amd import ensemble, host
     import particlerobotsimulations_amd as pb
-    prewarm = device_prewarm(pb, 250_000, LATTICE_PITCH, args.prewarm_ms)
+    warm = DevicePrewarm(pb, 250_000, LATTICE_PITCH, args.prewarm_ms)
     batches = ensemble_batches(args.workload, rank, world, args.members_per_gpu)
     t_place = time.perf_counter()
     ens = [ensemble.LocalEnsemble(cfg, over, common) for cfg, common, over, _ in batches]
@@ -417,6 +425,7 @@ def run_ensemble_workload(args, rank, world, dist, torch):
             torch.cuda.synchronize()
             dist.barrier()
 
+    prewarm = warm.run()
     drive(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -594,7 +603,7 @@ def main():
         return
 
     n = args.bots
-    prewarm = device_prewarm(pb, n, args.pitch, args.prewarm_ms)
+    warm = DevicePrewarm(pb, n, args.pitch, args.prewarm_ms)
     sim = make_sim(pb, n, args.pitch, seed=1 + rank)
     cfg = sim.config()
     assert cfg["force_variant"] == 2, cfg  # `value` is always the exact kernel
@@ -605,6 +614,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    prewarm = warm.run()
     sim.step(args.warmup)
     barrier()
     s0 = sim.stats()
