@@ -236,12 +236,16 @@ class DevicePrewarm:
             d, m = self.scratch.step_timed(100)
             steps += d
             ms += m
-        self.scratch.close()
-        self.scratch = None
+        # (closed later, by done(): freeing its buffers here would leave the device idle for milliseconds)
         self.info = {"ms": ms, "steps": steps,
                      "what": "a scratch copy of the workload stepped right before the measured simulation's warm-up "
                              "steps, to bring the device out of its idle power state; not part of warmup/steps"}
         return self.info
+
+    def done(self):
+        if self.scratch is not None:
+            self.scratch.close()
+            self.scratch = None
 
 
 def profiled_traffic():
@@ -432,6 +436,7 @@ def run_ensemble_workload(args, rank, world, dist, torch):
     done = drive(args.steps)
     barrier()
     wall = time.perf_counter() - t0
+    warm.done()
     assert all(d == args.steps for d in done), (done, args.steps)
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
@@ -622,6 +627,7 @@ def main():
     done, dev_ms = sim.step_timed(args.steps)
     barrier()
     wall = time.perf_counter() - t0
+    warm.done()
     s1 = sim.stats()
     assert done == args.steps, (done, args.steps)
 
