@@ -29,6 +29,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["bound"] == "valu" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert d["config"]["force_variant"] == 2 and d["config"]["lanes_per_bot"] in (1, 4) and d["config"]["resident"] == 0
     assert 500.0 < r["shader_clock_mhz"] < 2600.0, r["shader_clock_mhz"]
+    assert d["device_prewarm"]["steps"] >= 100 and d["device_prewarm"]["ms"] >= 100.0   # disclosed, not timed
     la = d["large_arena"]
     assert la["bots"] == 8_000_000 and la["finite_at_end"] and la["us_per_step"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
