@@ -10,6 +10,7 @@ int main(int argc, char **argv) {
     orc_params_defaults(&P);
     if (orc_load_cfg(&P, path)) return 1;
     P.time_to_dead = 0.05f; P.light_shadow = (k % 3);
+    P.rngKind = k % 3; /* counter generator, cuRAND-compatible XORWOW, rocRAND-seeded XORWOW */
     orc_params_derive(&P, 0, 0.0f);
     OrcSim *s = orc_sim_create(&P);
     orc_sim_reset(s, 0);
@@ -19,6 +20,13 @@ int main(int argc, char **argv) {
     rewind(fp);
     fclose(fp);
     orc_sim_destroy(s);
+  }
+  {
+    uint32_t u[32], rows[800];
+    float z[3 * 50];
+    orc_xorwow_outputs(1, 0xFFFFFFFFFFFFull, 70000u, 32, u);
+    orc_xorwow_normals(2, 9u, 50, 3, z);
+    orc_xorwow_jump_rows(rows);
   }
   printf("oracle sanitize done\n");
   return 0;

@@ -13,6 +13,10 @@ int pbHostWriteFrame(void *, const char *path, int w, int h, float cx, float cy,
 unsigned pbHostNumBots(void *);
 int pbHostGetArray(void *, int which, void *out);
 void *pbEnsembleCreate(const char *cfg, const char *common, const char **members, int n);
+void pbHostXorwowOutputs(int kind, unsigned long long seed, unsigned sub, unsigned count, unsigned *out);
+void pbHostXorwowNormals(int kind, unsigned seed, unsigned nbots, unsigned draws, float *out);
+int pbEnsembleShard(int nmembers, int rank, int world);
+int pbEnsembleAssemble(int nmembers, int world, int rows, const float *gathered, float *out);
 }
 int main(int argc, char **argv) {
   const char *root = argv[1];
@@ -21,7 +25,7 @@ int main(int argc, char **argv) {
   for (const char *nm : names) {
     char path[512];
     snprintf(path, sizeof path, "%s/examples/%s", root, nm);
-    for (const char *place : {"random", "hex", "grid", "line", "blob", "blob_upleft", "lighttest7", "square"}) {
+    for (const char *place : {"random", "hex", "grid", "line", "blob", "blob_upleft", "lighttest7", "square", "fastblob"}) {
       char over[128];
       snprintf(over, sizeof over, "pb_placement\n%s\ntime_to_dead\n0", place);
       void *h = pbHostCreate(path, over, 2);
@@ -45,6 +49,25 @@ int main(int argc, char **argv) {
     void *h = pbHostCreate(path, over, 2);
     pbHostReset(h);
     pbHostDestroy(h);
+  }
+  // O(N) blob at a size where the open list churns, payload mode included
+  for (const char *cfgname : {"example.cfg", "example_object_transport.cfg"}) {
+    char path[512];
+    snprintf(path, sizeof path, "%s/examples/%s", root, cfgname);
+    void *h = pbHostCreate(path, "nCells\n20000\npb_placement\nfastblob", 2);
+    pbHostReset(h);
+    pbHostDestroy(h);
+  }
+  // XORWOW on the host (jump table build, subsequence skips, Box-Muller) and the gather layout helpers
+  {
+    std::vector<unsigned> u(64);
+    pbHostXorwowOutputs(1, 5555ull, 12345u, 64, u.data());
+    pbHostXorwowOutputs(2, 0xFFFFFFFFFFFFull, 0xFFFFFFFFu, 64, u.data());
+    std::vector<float> z(3 * 257);
+    pbHostXorwowNormals(1, 7u, 257, 3, z.data());
+    const int members = 11, world = 4, rows = 3, per = pbEnsembleShard(members, 0, world);
+    std::vector<float> gathered((size_t)world * per * rows * 4, 1.0f), out((size_t)members * rows * 4);
+    if (pbEnsembleAssemble(members, world, rows, gathered.data(), out.data()) != 0) return 1;
   }
   // ensemble creation builds members on threads, then fails cleanly without a GPU
   char path[512];
