@@ -392,14 +392,16 @@ def ensemble_batches(workload, rank, world, members_per_gpu):
     return [(ex("example_dead_cells.cfg"), common, over, ids)]
 
 
-def run_ensemble_workload(args, rank, world, dist, torch):
+def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, rank, world, dist, torch):
+    """K timesteps of an ensemble workload on every rank (member k on rank k mod N), then the path's one
+    exchange (the summary rows, over RCCL when there is a process group).  Collective: every rank calls
+    it.  Returns (result dict on rank 0 else None, this rank's batches)."""
     import threading
 
     import numpy as np
-    from particlerobotsimulations_amd import ensemble, host
-    import particlerobotsimulations_amd as pb
-    warm = DevicePrewarm(pb, 250_000, LATTICE_PITCH, args.prewarm_ms)
-    batches = ensemble_batches(args.workload, rank, world, args.members_per_gpu)
+    from particlerobotsimulations_amd import ensemble
+    warm = DevicePrewarm(pb, 250_000, LATTICE_PITCH, prewarm_ms)
+    batches = ensemble_batches(workload, rank, world, members_per_gpu)
     t_place = time.perf_counter()
     ens = [ensemble.LocalEnsemble(cfg, over, common) for cfg, common, over, _ in batches]
     t_place = time.perf_counter() - t_place
@@ -410,9 +412,6 @@ def run_ensemble_workload(args, rank, world, dist, torch):
         done = [0] * len(ens)
 
         def one(i):
-            if torch is not None and i > 0:
-                # HIP's current device is per host thread: a new thread starts on device 0
-                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
             done[i] = ens[i].run_steps(nsteps)
         th = [threading.Thread(target=one, args=(i,)) for i in range(1, len(ens))]
         for t in th:
@@ -430,57 +429,65 @@ def run_ensemble_workload(args, rank, world, dist, torch):
             dist.barrier()
 
     prewarm = warm.run()
-    drive(args.warmup)
+    drive(warmup)
     barrier()
     t0 = time.perf_counter()
-    done = drive(args.steps)
+    done = drive(steps)
     barrier()
     wall = time.perf_counter() - t0
     warm.done()
-    assert all(d == args.steps for d in done), (done, args.steps)
+    assert all(d == steps for d in done), (done, steps)
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     # the path's only exchange: every member's summary rows, gathered once over RCCL
-    total_members = args.members_per_gpu * world
+    total_members = members_per_gpu * world
     gathered = [ensemble.gather_summaries(e.rows, total_members, rank, world, dist,
                                           "cuda" if dist is not None else "cpu") for e in ens]
     bots = [e.n for e in ens]
+    for e in ens:
+        e.close()
+    if rank != 0:
+        return None, batches
+    per_gpu_bots = sum(b * members_per_gpu for b in bots)
+    achieved = ALG_BYTES_PER_PARTICLE_STEP * per_gpu_bots * steps / wall / 1e9
+    last = [g[:, -1] for g in gathered]
+    assert all(np.isfinite(l).all() for l in last), "an ensemble member went NaN"
+    return {
+        "value": world * per_gpu_bots * steps / wall, "unit": "particle-steps/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": wall * 1e3 / steps, "scaling": "weak",
+        "config": {"workload": f"{workload}: {ENSEMBLE_WORKLOADS[workload]}",
+                   "members_per_gpu": members_per_gpu * len(bots), "members_total": total_members * len(bots),
+                   "bots_per_member": bots, "dt": 0.01,
+                   "parallelism": (f"member k -> rank k mod {world}; one batched pbSim per .cfg per GPU; "
+                                   f"RCCL world size {dist.get_world_size()}" if dist is not None
+                                   else "one GPU, no process group"),
+                   "members_per_rank": [len(ensemble.shard(total_members, r, world)) * len(bots)
+                                        for r in range(world)]},
+        "sims_per_s": world * members_per_gpu * len(bots) / wall,
+        "placement_s": t_place, "device_prewarm": prewarm,
+        "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_resident (<= 1024-bot members) / k_force (larger members)",
+                     "note": "64 algorithmic bytes per particle-step over WALL time of the timed region "
+                             "(host-driven schedule included); small members are latency-bound (DESIGN.md 6b)"},
+        "summaries_last_row_time_comx_comy_dist": [[[float(x) for x in r] for r in l[:4]] for l in last],
+        "summary_rows_gathered": [list(g.shape) for g in gathered],
+    }, batches
+
+
+def run_ensemble_workload(args, rank, world, dist, torch):
+    import particlerobotsimulations_amd as pb
+    res, batches = measure_ensemble(pb, args.workload, args.members_per_gpu, args.steps, args.warmup, args.prewarm_ms,
+                                    rank, world, dist, torch)
     if rank == 0:
-        per_gpu_bots = sum(b * args.members_per_gpu for b in bots)
-        value = world * per_gpu_bots * args.steps / wall
-        achieved = ALG_BYTES_PER_PARTICLE_STEP * per_gpu_bots * args.steps / wall / 1e9
-        last = [g[:, -1] for g in gathered]
-        assert all(np.isfinite(l).all() for l in last), "an ensemble member went NaN"
-        out = {
-            "metric": "particle-steps/sec at 10^6 bots; achieved HBM GB/s vs peak; 1/2/4/8-GPU ensemble",
-            "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {ENSEMBLE_WORKLOADS[args.workload]}",
-                       "members_per_gpu": args.members_per_gpu * len(ens), "members_total": total_members * len(ens),
-                       "bots_per_member": bots, "dt": 0.01,
-                       "parallelism": f"member k -> rank k mod {world}; one batched pbSim per .cfg per GPU; "
-                                      f"RCCL world size {dist.get_world_size() if dist is not None else 1}"
-                                      if dist is not None else "one GPU, no process group",
-                       "members_per_rank": [len(ensemble.shard(total_members, r, world)) * len(ens)
-                                            for r in range(world)]},
-            "sims_per_s": world * args.members_per_gpu * len(ens) / wall,
-            "placement_s": t_place, "device_prewarm": prewarm,
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_resident (<= 1024-bot members) / k_force (larger members)",
-                         "note": "64 algorithmic bytes per particle-step over WALL time of the timed region "
-                                 "(host-driven schedule included); small members are latency-bound (DESIGN.md 6b)"},
-            "summaries_last_row_time_comx_comy_dist": [[[float(x) for x in r] for r in l[:4]] for l in last],
-            "summary_rows_gathered": [list(g.shape) for g in gathered],
-        }
+        out = {"metric": "particle-steps/sec at 10^6 bots; achieved HBM GB/s vs peak; 1/2/4/8-GPU ensemble",
+               "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+        out.update(res)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_ensemble(batches, min(args.cpu_seconds, 10.0))
         emit(out)
-    for e in ens:
-        e.close()
 
 
 def cpu_baseline_ensemble(batches, budget_s):
@@ -564,6 +571,7 @@ def main():
     ap.add_argument("--no-large-arena", action="store_true")
     ap.add_argument("--no-clock", action="store_true")
     ap.add_argument("--no-blob", action="store_true")
+    ap.add_argument("--no-ensemble-leg", action="store_true")
     ap.add_argument("--prewarm-ms", type=float, default=100.0,
                     help="device time of scratch work before the measured simulation (clock ramp); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the cpu_baseline sample")
@@ -646,6 +654,14 @@ def main():
         summaries = [[sim.time, cx, cy]]
     assert cx == cx and cy == cy, "simulation state went NaN: the benchmark workload is invalid"
 
+    # BASELINE's "1/2/4/8-GPU ensemble": configs[3] (obstacle + object-transport seed ensembles, 32 members of
+    # each per GPU, member k on rank k mod N, RCCL gather of the summary rows) measured beside the arena at
+    # every N, without touching `value`.  Collective: every rank runs it.
+    ens_leg = None
+    if not args.no_ensemble_leg:
+        sim.synchronize()
+        ens_leg, _ = measure_ensemble(pb, "ensemble4", 32, min(max(args.steps, 200), 4000), 20, 0.0, rank, world,
+                                      dist, torch)
     if rank == 0:
         launches = (s1["fused_launches"] - s0["fused_launches"]) + (s1["plain_launches"] - s0["plain_launches"])
         value = world * n * args.steps / wall
@@ -692,6 +708,8 @@ def main():
             "device_prewarm": prewarm,
             "summaries_time_comx_comy": summaries,
         }
+        if ens_leg is not None:
+            out["ensemble_leg"] = ens_leg
         sim.close()
         if world == 1 and not args.no_large_arena:
             out["large_arena"] = large_arena_leg(pb, args.pitch, 20, min(args.steps, 200))

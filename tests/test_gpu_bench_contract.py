@@ -30,6 +30,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["config"]["force_variant"] == 2 and d["config"]["lanes_per_bot"] in (1, 4) and d["config"]["resident"] == 0
     assert 500.0 < r["shader_clock_mhz"] < 2600.0, r["shader_clock_mhz"]
     assert d["device_prewarm"]["steps"] >= 100 and d["device_prewarm"]["ms"] >= 100.0   # disclosed, not timed
+    el = d["ensemble_leg"]   # BASELINE configs[3] measured beside the arena (what a SCALE run sees at every N)
+    assert el["config"]["bots_per_member"] == [500, 201] and el["config"]["members_per_gpu"] == 64 and el["value"] > 1e8
+    assert el["summary_rows_gathered"][0][0] == 32
     la = d["large_arena"]
     assert la["bots"] == 8_000_000 and la["finite_at_end"] and la["us_per_step"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
@@ -85,6 +88,7 @@ def test_arena_line_through_rccl_with_one_rank_and_gpus_flag_is_checked():
     d = _bench("--bots", "150000", "--steps", "40", "--warmup", "10", "--force-dist", "--no-cpu-baseline",
                "--no-survey-literal", "--no-streamlined", "--no-large-arena", "--no-blob")
     assert d["n_gpus"] == 1 and len(d["summaries_time_comx_comy"]) == 1 and d["value"] > 0
+    assert "RCCL world size 1" in d["ensemble_leg"]["config"]["parallelism"]   # the leg's gather went over RCCL
     import torch
     if torch.cuda.device_count() < 2:
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"],

@@ -157,7 +157,7 @@ def main():
                                "avg_launch_us_profiled": avg_ns / 1e3,
                                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
                                          "`python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline "
-                                         "--no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob`; FETCH_SIZE x2 (gfx950 wide-read correction) "
+                                         "--no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg`; FETCH_SIZE x2 (gfx950 wide-read correction) "
                                          "x1024, WRITE_SIZE x1024 (MI355X_MICROARCH.md, HBM section)"}, fh)
             print(f"- derived: HBM-side traffic per launch = read {fetch/1e6:.1f} MB (FETCH_SIZE x2 x1024) + "
                   f"write {write/1e6:.1f} MB = {(fetch+write)/1e6:.1f} MB; at {avg_ns/1e3:.1f} us/launch = "
