@@ -174,3 +174,41 @@ def test_large_blob_long_window_with_noise_and_resorts(orc):
     # dead bots never actuated; live ones did
     rad = g.get("rad")
     assert np.all(rad[dead != 0] == np.float32(P.min_radius)) and (rad[dead == 0] > np.float32(P.min_radius)).any()
+
+
+def test_thirty_two_million_bots_match_oracle_and_stay_sane(orc):
+    """32 x 10^6 bots (3.3 GB of state, 4096^2 grid, walls +-470): beyond every cache and past 2^24
+    slots (32-bit slot / byte-offset arithmetic, radix sort with 25-bit keys).  Two steps equal the
+    oracle bit for bit on every state array; 12 more keep the lattice's symmetric centroid and finite
+    state; throughput per bot is that of the 10^6 arena or better."""
+    import bench
+    import particlerobotsimulations_amd as pb
+    from particlerobotsimulations_amd import make_params
+    pb.legacy.cudaInit(0, None)
+    n = 32_000_000
+    P = orc.default_params(nCells=n, nDead=0, seed=1, phase_std=0.0, max_time=1e9, light_x=-460.0, light_y=0.0,
+                           grid=4096, arena_half=470.0)
+    sp, keep = simparams_from_orc(P)
+    sim = pb.Sim(sp, wall_half=470.0, keepalive=keep)
+    pos = bench.square_lattice(n, bench.LATTICE_PITCH)
+    assert np.abs(pos).max() < 470.0 - 0.2
+    sim.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
+                  phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
+    orc.lib().orc_set_num_threads(orc.usable_cpus())
+    osim = orc.Sim(P, reset=True, hex=True)
+    osim.set("pos", pos)
+    del pos
+    sim.step(2)
+    osim.run(2)
+    st = sim.get_state()
+    for key in STATE_KEYS:
+        assert_bit_equal(st[key], osim.get(key), f"32e6 bots, step 2: {key}")
+    osim.close()
+    del st
+    done, ms = sim.step_timed(12)
+    assert done == 12
+    cx, cy = sim.centroid()
+    assert abs(cx) < 0.05 and abs(cy) < 0.05
+    us_per_million = ms * 1e3 / 12 / 32.0
+    assert us_per_million < 150.0, us_per_million   # the 10^6-bot arena costs ~115 us per step
+    sim.close()
