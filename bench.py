@@ -295,11 +295,13 @@ def valu_roofline(tr, n, avg_launch_us, clock_mhz):
     return out
 
 
-def measure_clock(pb, sim, steps, ms_per_step):
+def measure_clock(pb, sim, ms_per_step, span=0.15):
     """Shader clock held while the force kernel runs: a sleeping sampler wave on its own stream spans
-    ~80 % of `steps` more steps of the same simulation (NOT part of `value`'s timed region)."""
+    `span` seconds of real time while the same simulation keeps stepping (1.3 x the span's worth of
+    steps, so the sampler never sees an idle device; NOT part of `value`'s timed region)."""
     try:
-        span = max(0.02, min(5.0, 0.8 * steps * ms_per_step * 1e-3))
+        steps = int(span * 1.3 / max(ms_per_step * 1e-3, 1e-6)) + 50
+        sim.step(200)                # the legs before this one may have let the clocks drop
         smp = pb.ClockSample(span)
         sim.step(steps)
         sim.synchronize()
@@ -672,7 +674,7 @@ def main():
         tr = profiled_traffic() if n == 1_000_000 else None
         clock_mhz, clock_span = (None, None)
         if world == 1 and not args.no_clock:
-            clock_mhz, clock_span = measure_clock(pb, sim, min(args.steps, 2400), avg_launch_s * 1e3)
+            clock_mhz, clock_span = measure_clock(pb, sim, avg_launch_s * 1e3)
         out = {
             "metric": "particle-steps/sec at 10^6 bots; achieved HBM GB/s vs peak; 1/2/4/8-GPU ensemble",
             "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
