@@ -13,6 +13,7 @@
 // Rank 0 prints one JSON line and, with --out, writes the gathered rows as float32 [M][rows][4].
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -20,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <limits>
 #include <string>
 #include <thread>
@@ -62,13 +64,19 @@ static bool publishId(const std::string &path, const ncclUniqueId &id) {
   return rename(tmp.c_str(), path.c_str()) == 0;
 }
 
+// A file left behind by an earlier, crashed launch with the same port must not be taken for this
+// launch's id: only a file written no earlier than a minute before this process started counts.
 static bool fetchId(const std::string &path, ncclUniqueId *id, double timeoutSeconds) {
   const auto t0 = std::chrono::steady_clock::now();
+  const time_t started = time(nullptr);
   for (;;) {
-    if (FILE *f = fopen(path.c_str(), "rb")) {
-      const bool ok = fread(id, sizeof *id, 1, f) == 1;
-      fclose(f);
-      if (ok) return true;
+    struct stat sb;
+    if (stat(path.c_str(), &sb) == 0 && sb.st_mtime >= started - 60) {
+      if (FILE *f = fopen(path.c_str(), "rb")) {
+        const bool ok = fread(id, sizeof *id, 1, f) == 1;
+        fclose(f);
+        if (ok) return true;
+      }
     }
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSeconds) return false;
     std::this_thread::sleep_for(std::chrono::milliseconds(20));
