@@ -2,7 +2,8 @@
 every re-sort and phase update of the real schedule -- on the GPU engine and on the CPU oracle,
 compared bit for bit at checkpoints.
 
-  python tests/soak_long_run.py examples/example.cfg 720000 [checkpoint_every=60000]
+  python tests/soak_long_run.py examples/example.cfg 720000 [checkpoint_every=60000] [rng=0|1|2]
+(rng: 0 the counter generator, 1 the cuRAND-compatible XORWOW, 2 the rocRAND-seeded XORWOW)
 """
 import os
 import sys
@@ -21,14 +22,18 @@ def main():
     from helpers import assert_bit_equal, simparams_from_orc
     cfg, steps = sys.argv[1], int(sys.argv[2])
     every = int(sys.argv[3]) if len(sys.argv) > 3 else 60000
-    P = orc.load_cfg(cfg)
+    rng = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    P = orc.load_cfg(cfg, rngKind=rng)
     P.max_time = 1e9
     pb.legacy.cudaInit(0, None)
     if P.nDead > 0:
-        return class_level(cfg, steps, every)  # the dead-bot draw is the class's job: compare through it
+        return class_level(cfg, steps, every, rng)  # the dead-bot draw is the class's job: compare through it
     osim = orc.Sim(P, reset=True)
     sp, keep = simparams_from_orc(P)
     gsim = pb.Sim(sp, keepalive=keep)
+    if rng:
+        from particlerobotsimulations_amd import _capi
+        _capi.check(_capi.lib().pbSimSetRng(gsim._h, rng))
     gsim.set_state(pos=osim.get("pos"), vel=osim.get("vel"), rad=osim.get("rad"), phase=osim.get("phase"),
                    dead=osim.get("dead"))
     done = 0
@@ -51,17 +56,17 @@ def main():
               flush=True)
     s = gsim.stats()
     print(f"OK {os.path.basename(cfg)}: {P.nCells} bots x {steps} steps bit-identical; {s['resorts']} re-sorts, "
-          f"{s['phase_updates']} phase updates; GPU {tg:.1f} s, oracle (1 thread) {to:.1f} s")
+          f"{s['phase_updates']} phase updates, rng kind {rng}; GPU {tg:.1f} s, oracle (1 thread) {to:.1f} s")
 
 
-def class_level(cfg, steps, every):
+def class_level(cfg, steps, every, rng=0):
     """class Particlebot (placement + dead-bot draw from its private generator + fused engine) against
     the oracle's whole-simulation object"""
     from oracle import orclib as orc
     from particlerobotsimulations_amd import host
     from helpers import assert_bit_equal
-    h = host.HostSim(cfg, engine="fused", max_time="1e9")   # product first: creating it calls srand()
-    P = orc.load_cfg(cfg)
+    h = host.HostSim(cfg, engine="fused", max_time="1e9", pb_rng=["pbrng", "curand", "rocrand"][rng])
+    P = orc.load_cfg(cfg, rngKind=rng)   # (product first: creating it calls srand())
     P.max_time = 1e9
     osim = orc.Sim(P, reset=True)
     done = 0
