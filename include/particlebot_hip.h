@@ -154,7 +154,8 @@ int pbSimCreate(pbSim **out, const SimParams *params, float wallHalf);
 void pbSimDestroy(pbSim *sim);
 
 /* A BATCH of nsims independent simulations (an ensemble: seeds, sweep points) stepped together by
- * the same kernel launches: params is an array of nsims blocks (at most 2^28 bots in total).  All
+ * the same kernel launches: params is an array of nsims blocks (at most 2^32 - 32 bots in total: slots are 32-bit;
+ * from 2^28 bots on the throughput sweep switches from 32-bit to 64-bit byte offsets).  All
  * members must share nCells,
  * the grid, max_time, phase_update_interval, control and payload mode (nDead == -1 or not);
  * everything else (seed, light, obstacles, physics constants) may differ.  pbSimStep & co. advance

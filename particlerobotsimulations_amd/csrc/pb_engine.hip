@@ -210,7 +210,7 @@ struct PbSegCache {
 // flattened neighbour list at a time, then every lane of the group adds the L terms in list order
 // (ds_swizzle broadcasts inside the group), so the sums -- and their order -- are those of L == 1.
 // The serial chain per bot shrinks ~L/2-fold at ~2x the total VALU work.
-template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, bool CACHED, class PR, class VL>
+template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, bool CACHED, class PR, class VL, class OffT = uint32_t>
 __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn,
                                         const uint32_t *__restrict__ cellS, uint32_t base, uint32_t s,
                                          uint32_t sub, const float4 &me, const float2 &v, float att1, PbForce &F,
@@ -299,10 +299,12 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
     //    the array (spare elements) and is never evaluated.
     const char *const prBytes = (const char *)&prIn[0];
     const char *const velBytes = (const char *)&velIn[0];
-    const uint32_t selfOff = s * 16u;
-    auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
-    auto vat = [&](uint32_t off) __attribute__((always_inline)) { return *(const float2 *)(velBytes + (off >> 1)); };
-    auto one = [&](const float4 &q, const float2 &vq, uint32_t off) __attribute__((always_inline)) {
+    // OffT: 32-bit byte offsets (batches below 2^28 bots: one add and one compare per trip, loads with a
+    // scalar base + 32-bit vector offset) or 64-bit ones (larger batches, up to 2^32 slots)
+    const OffT selfOff = (OffT)s * 16u;
+    auto at = [&](OffT off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
+    auto vat = [&](OffT off) __attribute__((always_inline)) { return *(const float2 *)(velBytes + (off >> 1)); };
+    auto one = [&](const float4 &q, const float2 &vq, OffT off) __attribute__((always_inline)) {
       const bool live[1] = {off != selfOff};
       const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
       const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
@@ -313,18 +315,18 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
     };
     // byte offsets [lo, hi) of segment si; empty beyond the last one and for the second range of a
     // row away from the x-wrap
-    auto bounds = [&](int si, uint32_t &lo, uint32_t &hi) __attribute__((always_inline)) {
+    auto bounds = [&](int si, OffT &lo, OffT &hi) __attribute__((always_inline)) {
       lo = hi = selfOff;
       if (si < 10) {
         const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
-        lo = (cellS[row + ((si & 1) ? 0u : mx0)] - base) * 16u;
-        hi = (cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base) * 16u;
+        lo = (OffT)(cellS[row + ((si & 1) ? 0u : mx0)] - base) * 16u;
+        hi = (OffT)(cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base) * 16u;
       }
     };
     // segment numbers advance by 2 (one range per grid row) except for a lane at the x-wrap, whose
     // rows split into two ranges: per-lane stride, the wave runs until its last lane is done
     const int stride = nseg == 1 ? 2 : 1;
-    uint32_t loA, hiA, loB, hiB;
+    OffT loA, hiA, loB, hiB;
     bounds(0, loA, hiA);
     bounds(stride, loB, hiB);
     float4 qA = at(loA);
@@ -333,7 +335,7 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
 #pragma unroll 1
     for (int si = 0; si < 10; si += stride) {
       if (si == 4) PB_TL_STAMP(5);
-      const uint32_t lo = loA, end = hiA;
+      const OffT lo = loA, end = hiA;
       float4 q0 = qA;
       float2 v0 = vA;
       loA = loB;
@@ -342,7 +344,7 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
       vA = vat(loA);
       bounds(si + 2 * stride, loB, hiB);   // bounds of the one after
       if (lo < end) {
-        uint32_t off = lo;
+        OffT off = lo;
         for (;;) {
           const float4 q1 = at(off + 16u);
           const float2 v1 = vat(off + 16u);
@@ -487,12 +489,12 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
   }
 }
 
-template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, class PR, class VL>
+template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, class OffT, class PR, class VL>
 __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn, const uint32_t *__restrict__ cellS,
                                         uint32_t base, uint32_t s, uint32_t sub, const float4 &me, const float2 &v,
                                         float att1, PbForce &F) {
   PbSegCache none;
-  pbSweepC<PAYLOAD, FLAT, FAST, L, NB, false>(P, prIn, velIn, cellS, base, s, sub, me, v, att1, F, none);
+  pbSweepC<PAYLOAD, FLAT, FAST, L, NB, false, PR, VL, OffT>(P, prIn, velIn, cellS, base, s, sub, me, v, att1, F, none);
 }
 
 // Forces + kick of step n (impl.cuh:657-831); with FUSE also radius + integration of step n+1.
@@ -500,7 +502,8 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
 // pair evaluation instead of the reference-shaped branches (pbPair).
 // FASTOK: the simulation passed pbFastMathAllowed, so waves whose lanes all pass
 // pbLaneFastMathOk may use the exact fast sqrt/division forms.
-template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB>
+// BIG: 64-bit byte offsets in the neighbour sweep (batches of 2^28 bots and more, throughput form only).
+template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB, bool BIG = false>
 __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) void k_force(const PbDevParams *__restrict__ params,
                                                 const float4 *__restrict__ prIn, const float2 *__restrict__ velIn,
                                                 float4 *__restrict__ prOut, float2 *__restrict__ velOut,
@@ -537,10 +540,11 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
   F.fr = 0.0f * absR[s];  // impl.cuh:688
 
   // wave-uniform choice: the fast exact forms need every lane's coordinates away from zero
+  using OffT = typename std::conditional<BIG, uint64_t, uint32_t>::type;
   if (FLAT && FASTOK && __all(pbLaneFastMathOk(me.x, me.y)))
-    pbSweep<PAYLOAD, FLAT, true, L, NB>(P, prIn, velIn, cellS, 0u, s, sub, me, v, att1, F);
+    pbSweep<PAYLOAD, FLAT, true, L, NB, OffT>(P, prIn, velIn, cellS, 0u, s, sub, me, v, att1, F);
   else
-    pbSweep<PAYLOAD, FLAT, false, L, NB>(P, prIn, velIn, cellS, 0u, s, sub, me, v, att1, F);
+    pbSweep<PAYLOAD, FLAT, false, L, NB, OffT>(P, prIn, velIn, cellS, 0u, s, sub, me, v, att1, F);
   pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
   pbFrictionAndKick(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
 
@@ -1289,14 +1293,14 @@ inline dim3 gridOf(const pbSim *S) { return dim3(cdiv(S->n, TILE), S->nsims); }
 // several batches from several threads must not have to remember that
 inline void useDevice(const pbSim *S) { (void)hipSetDevice(S->device); }
 
-template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB>
+template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB, bool BIG = false>
 void launchForceT(pbSim *S, int c, int o, float dt, float tNext, int doRadiusNext) {
   const uint32_t tiles = cdiv(S->n, TILE / L);
   // XCD-aware order only pays when a simulation spans many tiles
   const uint32_t perXcd = (L == 1 && tiles >= 64u) ? cdiv(tiles, 8u) : 0u;
   const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
   // (debugLdsBytes: an occupancy experiment -- unused dynamic LDS that only limits workgroups per CU)
-  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK, L, NB>), grid, dim3(TILE), S->debugLdsBytes, S->stream, S->dP, S->pr[c],
+  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK, L, NB, BIG>), grid, dim3(TILE), S->debugLdsBytes, S->stream, S->dP, S->pr[c],
                      S->vel[c], S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c],
                      S->cellS, S->n, dt, tNext, doRadiusNext, perXcd);
 }
@@ -1356,12 +1360,14 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
     return;
   }
   const int kind = plan.kind, form = plan.form;
+  const bool big = S->total >= (1u << 28) - 8u;  // 32-bit byte offsets into posrad stop at 2^28 slots
 #define PB_CASE(F, PL, K, FL, FA)                                                                        \
   if (fuse == F && payload == PL && kind == K) {                                                         \
     if (FL && form == 16) return launchForceT<F, PL, FL, FA, (FL ? 16 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 8) return launchForceT<F, PL, FL, FA, (FL ? 8 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 4) return launchForceT<F, PL, FL, FA, (FL ? 4 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 2) return launchForceT<F, PL, FL, FA, (FL ? 2 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
+    if (FL && big) return launchForceT<F, PL, FL, FA, 1, 1, FL>(S, c, o, dt, tNext, doRadiusNext);                                   \
     return launchForceT<F, PL, FL, FA, 1, (FL ? PB_THROUGHPUT_NB : 1)>(S, c, o, dt, tNext, doRadiusNext);                            \
   }
   PB_CASE(true, true, 0, false, false)
@@ -1633,10 +1639,11 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
       return PB_ERR_ARG;
     }
   }
-  // (the neighbour sweeps address posrad with 32-bit BYTE offsets, 16 bytes per bot: 2^28 bots)
-  if ((uint64_t)params[0].nCells * (uint64_t)nsims > (1ull << 28) - 8ull ||
+  // (slots are 32-bit; below 2^28 bots the throughput sweep addresses posrad with 32-bit BYTE offsets,
+  //  above it switches to 64-bit ones)
+  if ((uint64_t)params[0].nCells * (uint64_t)nsims > 0xFFFFFFE0ull ||
       (uint64_t)params[0].numCells * (uint64_t)nsims > 0xFFFFFFF0ull) {
-    g_lastError = "pbSimCreateBatch: batch too large (at most 2^28 bots and 2^32 cells in one batch)";
+    g_lastError = "pbSimCreateBatch: batch too large (at most 2^32 bots and 2^32 cells in one batch)";
     return PB_ERR_ARG;
   }
   if (nsims > 65535) {  // members ride in gridDim.y

@@ -81,9 +81,9 @@ def test_engine_error_paths_without_a_gpu(capi):
     other, k2 = capi.make_params({"gridSize": (512, 512), "numCells": 512 * 512, "nCells": 11})
     arr = (capi.SimParams * 2)(ok, other)
     assert L.pbSimCreateBatch(C.byref(h), arr, 2, 0.0) == 2 and b"must share" in L.pbGetLastErrorString()
-    big, k3 = capi.make_params({"gridSize": (512, 512), "numCells": 512 * 512, "nCells": 200_000_000})
-    arr2 = (capi.SimParams * 2)(big, big)
-    assert L.pbSimCreateBatch(C.byref(h), arr2, 2, 0.0) == 2 and b"2^28" in L.pbGetLastErrorString()
+    big, k3 = capi.make_params({"gridSize": (512, 512), "numCells": 512 * 512, "nCells": 2_000_000_000})
+    arr2 = (capi.SimParams * 3)(big, big, big)
+    assert L.pbSimCreateBatch(C.byref(h), arr2, 3, 0.0) == 2 and b"2^32" in L.pbGetLastErrorString()
     # a valid request: no device here
     import torch
     if not torch.cuda.is_available():
