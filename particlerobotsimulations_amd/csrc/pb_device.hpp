@@ -85,14 +85,15 @@ static inline void pbFlattenParams(PbDevParams &d, const SimParams &p, float wal
   }
 }
 
-// Per-simulation precondition of the fast exact forms.  With the arena at most 2048 half-wide any
-// two bots (aliased cells pair bots from opposite ends of the arena) are less than 2^12.5 apart, so
-// a nonzero unit-vector component |n| = |r|/dist is >= 2^-44 / 2^12.5 > 2^-57; with every attraction
-// constant a pair can see 0 or in [2^-40, 2^30], pbDiv2Fast's numerators A*n are 0 or >= 2^-97
-// (domain: >= 2^-100) and its quotients A*n/gap^2 >= 2^-97 / 2^25 = 2^-122 stay normal.
+// Per-simulation precondition of the fast exact forms.  With the arena at most 4096 half-wide any
+// two bots (aliased cells pair bots from opposite ends of the arena) are less than 2^13.5 apart, so
+// a nonzero unit-vector component |n| = |r|/dist is >= 2^-44 / 2^13.5 = 2^-57.5; with every attraction
+// constant a pair can see 0 or in [2^-40, 2^30], pbDiv2Fast's numerators A*n are 0 or >= 2^-97.5
+// (domain: >= 2^-100) and its quotients A*n/gap^2 >= 2^-97.5 / 2^27 = 2^-124.5 stay normal (an arena
+// twice as wide would reach 2^-127.5: denormal, outside the domain).
 static inline bool pbFastMathAllowed(const PbDevParams &d) {
   auto okA = [](float a) { return a == 0.0f || (a >= 0x1p-40f && a <= 0x1p30f); };
-  bool ok = okA(d.attraction) && d.wallHalf <= 2048.0f && d.wallHalf > 0.0f;
+  bool ok = okA(d.attraction) && d.wallHalf <= 4096.0f && d.wallHalf > 0.0f;
   if (d.nDead == -1) {
     const float a1 = d.attraction * d.attractionFactor;
     ok = ok && okA(a1) && okA(a1 * d.attractionFactor);
