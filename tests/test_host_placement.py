@@ -187,7 +187,7 @@ def test_fastblob_is_deterministic_linear_and_handles_the_payload(host):
     assert_bit_equal(a.get("pos"), b.get("pos"), "same seed, same blob")
     pos = a.get("pos")
     assert pos[-1, 1] == 0.0 and pos[-1, 0] < pos[:-1, 0].min()  # payload left of the blob (particlebot.cpp:731-735)
-    # roughly linear in N: 10x the bots within ~25x the time even on a noisy box (the reference rule: ~32x)
+    # roughly linear in N: 10x the bots well within 40x the time even on a noisy box (the reference rule: ~32x on a quiet one)
     big = dict(pb_grid_size="2048", pb_arena_half="240")
     t = []
     for n in (20000, 200000):
@@ -197,4 +197,4 @@ def test_fastblob_is_deterministic_linear_and_handles_the_payload(host):
         t.append(time.perf_counter() - t0)
         p = s.get("pos")
         assert np.isfinite(p).all() and np.abs(p).max() < 240.0
-    assert t[1] < 25 * t[0] + 0.5, t
+    assert t[1] < 40 * t[0] + 1.0, t   # (generous: the point is "not quadratic", on a possibly noisy host)
