@@ -7,15 +7,18 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; nothing under
  * particlerobotsimulations_amd/ links, imports or executes it.
  *
- * Pinning status: the reference cannot be built in this image under the build rules (it needs the
- * CUDA runtime + cuRAND headers, Thrust, GLEW, freeglut and OpenCV, none of which exist here), and
- * the reference ships no tests or golden vectors.  The oracle is pinned BIT-EXACTLY against the
- * position snapshots in tests/golden/ref_probe/ (outputs of the unmodified reference sources run on
- * the CPU by the survey session): initial placement and steps 1..20000 of
- * the example.cfg-like run.  Three things stay "parity unpinned" (no CUDA toolchain to check
- * against): cuRAND XORWOW noise (the oracle uses its own counter RNG, orc_normal()), the CUDA fast
- * intrinsic __powf(x,2) (restated as x*x), and nvcc's FMA contraction choices (restated with no
- * contraction; build with -ffp-contract=off).
+ * Pinning status: PARITY UNPINNED in the strict sense.  The reference cannot be built in this image
+ * under the build rules (it needs the CUDA runtime + cuRAND headers, Thrust, GLEW, freeglut and OpenCV,
+ * none of which exist here, and stand-in headers are not allowed), and it ships no tests or golden
+ * vectors.  What the oracle IS checked against, bit for bit: the position snapshots in
+ * tests/golden/ref_probe/ -- outputs of the unmodified reference sources run on the CPU by the survey
+ * session against its own stand-in CUDA/GL headers: initial placement and
+ * steps 1..20000 of the example.cfg-like run; and, for the XORWOW generator (generator 2 below),
+ * rocRAND's own host-callable xorwow_engine and precomputed jump matrices (tests/test_xorwow.py).
+ * Unpinned in any sense (no CUDA toolchain to check against): cuRAND's four seeding constants and
+ * the device logf/__sincosf inside curand_normal (the default noise generator is this project's
+ * counter RNG, orc_normal()), the CUDA fast intrinsic __powf(x,2) (restated as x*x), and nvcc's FMA
+ * contraction choices (restated with no contraction; build with -ffp-contract=off).
  *
  * Arithmetic rules of the restatement (identical in the HIP kernels so that the two are
  * bit-identical by construction):
