@@ -1275,6 +1275,7 @@ struct pbSim {
   int variant = 2;  // force kernel: 0 reference-shaped branches, 1 branch-free, 2 (default) + fast exact math
   int resident = 0;     // 0 automatic, 1 never, 2 whenever the simulation fits one workgroup (n <= 1024)
   int lanesPerBot = 0;  // lanes per bot of the per-step force kernel: 0 automatic; 1 (throughput form), 2, 4, 8, 16
+  bool debugForceBig = false;  // PB_DEBUG_FORCE_BIG under PB_ALLOW_ENV_OVERRIDES=1
   unsigned debugLdsBytes = 0;  // PB_DEBUG_LDS_BYTES under PB_ALLOW_ENV_OVERRIDES=1 (tools/occupancy_sweep.py --lds)
   int rng = 0;          // phase noise: 0 PB-RNG v1 (counter based), 1 cuRAND-compatible XORWOW (pb_xorwow.hpp)
   pbSimStats stats{};
@@ -1360,7 +1361,8 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
     return;
   }
   const int kind = plan.kind, form = plan.form;
-  const bool big = S->total >= (1u << 28) - 8u;  // 32-bit byte offsets into posrad stop at 2^28 slots
+  // 32-bit byte offsets into posrad stop at 2^28 slots (debugForceBig: tests run the 64-bit form on small batches)
+  const bool big = S->total >= (1u << 28) - 8u || S->debugForceBig;
 #define PB_CASE(F, PL, K, FL, FA)                                                                        \
   if (fuse == F && payload == PL && kind == K) {                                                         \
     if (FL && form == 16) return launchForceT<F, PL, FL, FA, (FL ? 16 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
@@ -1678,6 +1680,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     if (const char *v = getenv("PB_LANES_PER_BOT")) rc |= pbSimSetLanesPerBot(S, atoi(v));
     if (const char *v = getenv("PB_RESIDENT")) rc |= pbSimSetResident(S, atoi(v));
     if (const char *v = getenv("PB_DEBUG_LDS_BYTES")) S->debugLdsBytes = (unsigned)std::min(atol(v), 65536L);
+    if (const char *v = getenv("PB_DEBUG_FORCE_BIG")) S->debugForceBig = atoi(v) != 0;
     if (rc != PB_OK) {
       g_lastError = "pbSimCreateBatch: PB_FORCE_VARIANT / PB_LANES_PER_BOT / PB_RESIDENT out of range";
       delete S;

@@ -209,3 +209,37 @@ def test_random_parameter_sets(pb, orc, trial):
         assert gsim.step(k - step, sort_interval=si) == k - step
         step = k
         compare(osim, gsim, f"trial {trial} n={n} step {k}")
+
+
+@pytest.mark.parametrize("case", ["payload_obstacles", "wrap_walls"])
+def test_sixty_four_bit_offset_sweep_on_a_small_batch(pb, orc, case, monkeypatch):
+    """The throughput sweep's 64-bit-offset form (k_force<..., BIG>, used from 2^28 bots: one arena of 10^9
+    bots in tests/soak_huge_arena.py) forced onto a few thousand bots: payload factors + obstacles, and the
+    x-wrap / aliased cells / wall clamps, bit for bit against the oracle through re-sorts."""
+    monkeypatch.setenv("PB_ALLOW_ENV_OVERRIDES", "1")
+    monkeypatch.setenv("PB_DEBUG_FORCE_BIG", "1")
+    rng = np.random.default_rng(77)
+    if case == "payload_obstacles":
+        n = 4001
+        P = orc.default_params(nCells=n, nDead=-1, seed=3, phase_std=0.6, max_time=1e9, attractionFactor=0.5,
+                               massFactor=2.0, radFactor=2.0, n_cir_obstacles=2, x_cir_obs=[2.0, 6.5],
+                               y_cir_obs=[0.5, -1.0], r_cir_obs=[0.4, 0.3], nobstacles=1, x1obs=[3.0], x2obs=[3.2],
+                               y1obs=[-2.0], y2obs=[-0.6])
+        osim = orc.Sim(P, reset=True)
+        pos, vel, rad = osim.get("pos"), osim.get("vel"), osim.get("rad")
+    else:
+        n = 3000
+        P = orc.default_params(nCells=n, nDead=0, seed=4, phase_std=0.0, max_time=1e9)
+        osim = orc.Sim(P, reset=True)
+        pos, vel, rad = jittered_blob(n, 0.158, rng, center=(59.0, -59.5), jitter=0.12)   # at the wall and the grid wrap
+        osim.set("pos", pos), osim.set("vel", vel), osim.set("rad", rad)
+    sp, keep = simparams_from_orc(P)
+    gsim = pb.Sim(sp, keepalive=keep)
+    gsim.set_lanes_per_bot(1)
+    gsim.set_state(pos=pos, vel=vel, rad=rad, phase=osim.get("phase"), dead=osim.get("dead"))
+    step = 0
+    for k in (1, 30, 260):
+        osim.run(k - step, sort_interval=1.0)
+        assert gsim.step(k - step, sort_interval=1.0) == k - step
+        step = k
+        compare(osim, gsim, f"64-bit offsets, {case}, step {k}")
