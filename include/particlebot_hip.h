@@ -263,6 +263,7 @@ typedef struct pbSimConfig {
   int fast_math_ok;
   int payload;
   int rng; /* 0 PB-RNG v1 (default), 1 cuRAND-compatible XORWOW */
+  int offsets64; /* 1: the throughput sweep runs with 64-bit byte offsets (batches of 2^28 bots and more) */
 } pbSimConfig;
 int pbSimGetConfig(pbSim *sim, pbSimConfig *cfg);
 

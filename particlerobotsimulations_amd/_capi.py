@@ -73,7 +73,7 @@ class pbSimStats(C.Structure):
 
 class pbSimConfig(C.Structure):
     _fields_ = [("force_variant", C.c_int), ("force_kind", C.c_int), ("lanes_per_bot", C.c_int),
-                ("resident", C.c_int), ("fast_math_ok", C.c_int), ("payload", C.c_int), ("rng", C.c_int)]
+                ("resident", C.c_int), ("fast_math_ok", C.c_int), ("payload", C.c_int), ("rng", C.c_int), ("offsets64", C.c_int)]
 
 
 # every symbol include/particlebot_hip.h declares: name -> (restype, argtypes)

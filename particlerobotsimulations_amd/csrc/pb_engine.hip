@@ -2071,6 +2071,7 @@ int pbSimGetConfig(pbSim *S, pbSimConfig *cfg) {
   cfg->fast_math_ok = S->fastOk ? 1 : 0;
   cfg->payload = S->payload ? 1 : 0;
   cfg->rng = S->rng;
+  cfg->offsets64 = (p.form == 1 && p.kind >= 1 && !p.stream && (S->total >= (1u << 28) - 8u || S->debugForceBig)) ? 1 : 0;
   return PB_OK;
 }
 

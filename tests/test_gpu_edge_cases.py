@@ -236,6 +236,7 @@ def test_sixty_four_bit_offset_sweep_on_a_small_batch(pb, orc, case, monkeypatch
     sp, keep = simparams_from_orc(P)
     gsim = pb.Sim(sp, keepalive=keep)
     gsim.set_lanes_per_bot(1)
+    assert gsim.config()["offsets64"] == 1 and gsim.config()["lanes_per_bot"] == 1
     gsim.set_state(pos=pos, vel=vel, rad=rad, phase=osim.get("phase"), dead=osim.get("dead"))
     step = 0
     for k in (1, 30, 260):
