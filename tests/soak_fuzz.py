@@ -45,13 +45,18 @@ def one(pb, orc, trial, seed0):
         dead = (rng.random(n) < rng.uniform(0.05, 0.4)).astype(np.int32)
         osim.set("dead", dead)
     sp, keep = simparams_from_orc(P)
+    form = rng.choice(["auto", "l1", "l1big", "l2", "l4", "l8", "l16", "resident", "variant0", "variant1"])
+    os.environ["PB_ALLOW_ENV_OVERRIDES"] = "1"
+    os.environ["PB_DEBUG_FORCE_BIG"] = "1" if form == "l1big" else "0"   # the 64-bit-offset sweep on a small batch
     gsim = pb.Sim(sp, keepalive=keep)
     if kind:
         _capi.check(_capi.lib().pbSimSetRng(gsim._h, kind))
     gsim.set_state(pos=osim.get("pos"), vel=osim.get("vel"), rad=osim.get("rad"), phase=osim.get("phase"),
                    dead=osim.get("dead"))
-    form = rng.choice(["auto", "l1", "l2", "l4", "l8", "l16", "resident", "variant0", "variant1"])
-    if form.startswith("l"):
+    if form == "l1big":
+        gsim.set_lanes_per_bot(1)
+        assert gsim.config()["offsets64"] == 1
+    elif form.startswith("l"):
         gsim.set_lanes_per_bot(int(form[1:]))
     elif form == "resident":
         gsim.set_resident(2)
