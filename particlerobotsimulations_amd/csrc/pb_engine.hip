@@ -941,17 +941,70 @@ __global__ __launch_bounds__(TILE) void k_cell_scan(const uint32_t *__restrict__
 // particlebot.cpp:215-228 squares it: powf(light-x,2)+powf(light-y,2).  Non-negative floats order
 // like their bit patterns, so an integer min is exact and order-independent.  Two levels: one value
 // per workgroup (wave shuffles, then LDS), then one wave per simulation over those (k_min_final) --
-// thousands of atomicMin on one address took 46 us at 10^6 bots, this takes ~10.
+// thousands of atomicMax/Min on one address took 46 us at 10^6 bots, this takes ~10.
+//
+// NaN semantics of the reference loop (a simulation that has blown up): `min_d = (min_d < dist ? min_d :
+// dist)` in ORIGINAL bot order takes `dist` whenever the comparison is false, so a NaN distance
+// replaces the running minimum and the next bot's distance replaces the NaN: the loop's result is the
+// minimum over the bots AFTER the last NaN one (NaN itself if that is the last bot).  k_last_nan finds
+// that index per simulation (-1: none), k_min_dist2 then only admits bots with a larger original
+// index; both are two-level reductions.
+__global__ __launch_bounds__(TILE) void k_last_nan(const PbDevParams *__restrict__ params,
+                                                   const float4 *__restrict__ pr, const uint32_t *__restrict__ orig,
+                                                   uint32_t n, int *__restrict__ partial) {
+  const PbDevParams &P = params[blockIdx.y];
+  const uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  int last = -1;
+  if (l < n) {
+    const uint32_t s = blockIdx.y * n + l;
+    const float4 q = pr[s];
+    const float dx = P.light_x - q.x, dy = P.light_y - q.y;
+    const float d2 = dx * dx + dy * dy;
+    if (d2 != d2) last = (int)orig[s];
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int o = __shfl_xor(last, d, 64);
+    last = o > last ? o : last;
+  }
+  __shared__ int waveMax[TILE / 64];
+  if ((threadIdx.x & 63u) == 0u) waveMax[threadIdx.x >> 6] = last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int m = waveMax[0];
+#pragma unroll
+    for (int w = 1; w < TILE / 64; w++) m = waveMax[w] > m ? waveMax[w] : m;
+    partial[blockIdx.y * gridDim.x + blockIdx.x] = m;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_last_nan_final(const int *__restrict__ partial, uint32_t nb,
+                                                       int *__restrict__ out) {
+  int last = -1;
+  for (uint32_t b = threadIdx.x; b < nb; b += 64u) {
+    const int o = partial[blockIdx.x * nb + b];
+    last = o > last ? o : last;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int o = __shfl_xor(last, d, 64);
+    last = o > last ? o : last;
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = last;
+}
+
 __global__ __launch_bounds__(TILE) void k_min_dist2(const PbDevParams *__restrict__ params,
-                                                    const float4 *__restrict__ pr, uint32_t n,
+                                                    const float4 *__restrict__ pr, const uint32_t *__restrict__ orig,
+                                                    const int *__restrict__ lastNan, uint32_t n,
                                                     uint32_t *__restrict__ partial) {
   const PbDevParams &P = params[blockIdx.y];
   const uint32_t l = blockIdx.x * TILE + threadIdx.x;
   uint32_t bits = 0x7f800000u;  // +inf
   if (l < n) {
-    const float4 q = pr[blockIdx.y * n + l];
+    const uint32_t s = blockIdx.y * n + l;
+    const float4 q = pr[s];
     const float dx = P.light_x - q.x, dy = P.light_y - q.y;
-    bits = __float_as_uint(dx * dx + dy * dy);
+    if ((int)orig[s] > lastNan[blockIdx.y]) bits = __float_as_uint(dx * dx + dy * dy);  // (never NaN: those are <= lastNan)
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -1465,16 +1518,23 @@ int phaseUpdate(pbSim *S) {
   const uint32_t n = S->n;
   const int c = S->cur;
   const dim3 g = gridOf(S), b(TILE);
-  // (the per-workgroup minima borrow the centroid reduction's scratch: 16 bytes per workgroup there)
+  // (the per-workgroup partial results borrow the centroid reduction's scratch: 16 bytes per workgroup
+  //  there; dMin[nsims .. 2 nsims) holds the last-NaN indices)
   uint32_t *partial = (uint32_t *)S->comPartial;
-  hipLaunchKernelGGL(k_min_dist2, g, b, 0, S->stream, S->dP, S->pr[c], n, partial);
-  hipLaunchKernelGGL(k_min_final, dim3(S->nsims), dim3(64), 0, S->stream, partial, cdiv(n, TILE), S->dMin);
-  PB_TRY(hipMemcpyAsync(S->hMin, S->dMin, sizeof(uint32_t) * S->nsims, hipMemcpyDeviceToHost, S->stream));
+  int *lastNan = (int *)(S->dMin + S->nsims);
+  const uint32_t nb = cdiv(n, TILE);
+  hipLaunchKernelGGL(k_last_nan, g, b, 0, S->stream, S->dP, S->pr[c], S->orig[c], n, (int *)partial);
+  hipLaunchKernelGGL(k_last_nan_final, dim3(S->nsims), dim3(64), 0, S->stream, (const int *)partial, nb, lastNan);
+  hipLaunchKernelGGL(k_min_dist2, g, b, 0, S->stream, S->dP, S->pr[c], S->orig[c], lastNan, n, partial);
+  hipLaunchKernelGGL(k_min_final, dim3(S->nsims), dim3(64), 0, S->stream, partial, nb, S->dMin);
+  PB_TRY(hipMemcpyAsync(S->hMin, S->dMin, sizeof(uint32_t) * 2 * S->nsims, hipMemcpyDeviceToHost, S->stream));
   PB_TRY(hipStreamSynchronize(S->stream));
   for (uint32_t k = 0; k < S->nsims; k++) {
     float minD2;
     memcpy(&minD2, &S->hMin[k], sizeof(float));
     S->hMinD[k] = powf(minD2, 0.5f);
+    // the reference's loop ends on NaN when the LAST bot's distance is NaN (see k_last_nan)
+    if ((int)S->hMin[S->nsims + k] == (int)n - 1) S->hMinD[k] = nanf("");
   }
   PB_TRY(hipMemcpyAsync(S->dMinD, S->hMinD, sizeof(float) * S->nsims, hipMemcpyHostToDevice, S->stream));
   hipLaunchKernelGGL(k_phase, g, b, 0, S->stream, S->dP, S->pr[c], S->orig[c], S->phase[c], n, S->dMinD,
@@ -1723,13 +1783,13 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   PB_TRY_NEW(hipMalloc((void **)&S->cellS, sizeof(uint32_t) * G1 * nsims));
   PB_TRY_NEW(hipMalloc((void **)&S->hist, sizeof(uint32_t) * pbSortHistEntries(S->total)));
   PB_TRY_NEW(hipMalloc((void **)&S->slotOf, sizeof(uint32_t) * total));
-  PB_TRY_NEW(hipMalloc((void **)&S->dMin, sizeof(uint32_t) * nsims));
+  PB_TRY_NEW(hipMalloc((void **)&S->dMin, sizeof(uint32_t) * 2 * nsims));  // minima | last-NaN indices
   PB_TRY_NEW(hipMalloc((void **)&S->dMinD, sizeof(float) * nsims));
   PB_TRY_NEW(hipMalloc((void **)&S->stage, 36 * n));
   PB_TRY_NEW(hipMalloc((void **)&S->comPos, sizeof(float2) * total));
   PB_TRY_NEW(hipMalloc((void **)&S->comPartial, sizeof(double2) * cdiv(S->n, TILE) * nsims));
   PB_TRY_NEW(hipMalloc((void **)&S->comOut, sizeof(double2) * nsims));
-  PB_TRY_NEW(hipHostMalloc((void **)&S->hMin, sizeof(uint32_t) * nsims));
+  PB_TRY_NEW(hipHostMalloc((void **)&S->hMin, sizeof(uint32_t) * 2 * nsims));
   PB_TRY_NEW(hipHostMalloc((void **)&S->hMinD, sizeof(float) * nsims));
   PB_TRY_NEW(hipHostMalloc((void **)&S->hCom, sizeof(double2) * nsims));
   hipLaunchKernelGGL(k_iota, gridOf(S), dim3(TILE), 0, S->stream, S->orig[0], S->n);

@@ -244,3 +244,33 @@ def test_sixty_four_bit_offset_sweep_on_a_small_batch(pb, orc, case, monkeypatch
         assert gsim.step(k - step, sort_interval=1.0) == k - step
         step = k
         compare(osim, gsim, f"64-bit offsets, {case}, step {k}")
+
+
+@pytest.mark.parametrize("nan_at", [(0,), (5, 70), (149,), (3, 149)])
+def test_phase_update_follows_the_reference_loop_when_positions_are_nan(pb, orc, nan_at):
+    """A blown-up simulation: the reference's min-distance loop `min_d = (min_d < dist ? min_d : dist)`
+    (particlebot.cpp:217-227) lets a NaN distance replace the running minimum and the next bot's distance
+    replace the NaN, i.e. it returns the minimum over the bots AFTER the last NaN one (NaN if that is the
+    last bot).  The engine's on-device reduction must give the same phases (found by tests/soak_fuzz.py)."""
+    n = 150
+    P = orc.default_params(nCells=n, nDead=0, seed=21, phase_std=0.0, max_time=1e9, light_x=-3.0, light_y=2.0)
+    osim = orc.Sim(P, reset=True)
+    pos = osim.get("pos")
+    # make the bots BEFORE the last NaN index the closest to the light, so that ignoring NaNs would differ
+    pos[:max(nan_at)] += np.float32(-2.0)
+    for i in nan_at:
+        pos[i] = np.nan
+    osim.set("pos", pos)
+    sp, keep = simparams_from_orc(P)
+    gsim = pb.Sim(sp, keepalive=keep)
+    gsim.set_state(pos=pos, vel=osim.get("vel"), rad=osim.get("rad"), phase=osim.get("phase"), dead=osim.get("dead"))
+    osim.run(1)
+    gsim.step(1)
+    a, b = gsim.get_state()["phase"], osim.get("phase")
+    both_nan = np.isnan(a) & np.isnan(b)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert_bit_equal(np.where(both_nan, 0, a).astype(np.float32), np.where(both_nan, 0, b).astype(np.float32), "phase")
+    if max(nan_at) == n - 1:
+        assert np.isnan(b).all()
+    else:
+        assert np.isfinite(b[[i for i in range(n) if i not in nan_at]]).all()
