@@ -228,6 +228,16 @@ int pbSimSetResortEveryStep(pbSim *sim, int on);
  * replaces the throughput form (batches above 131072 bots, or lanes-per-bot forced to 1); smaller
  * batches keep running the exact kernels. */
 int pbSimSetForceVariant(pbSim *sim, int variant);
+/* The two per-bot magnitude sums of the force kernel, absForce_a (Sum|F_attr|) and absForce_r
+ * (Sum|F_rep|), are private scratch arrays of the reference (no getArray case, not in the dump);
+ * their only reader is the next step's radius actuation, which reads absForce_a solely under
+ * `if (params.constrained_contraction)` (particlebot_kernel_impl.cuh:167-169; 0 by default and in all
+ * shipped examples).  mode 0 (default): absForce_a is maintained only when some member of the batch
+ * has constrained_contraction set -- otherwise it is a dead value, the branch-free force kernels
+ * (variants 1 and 2, every lanes-per-bot form, the resident kernel) do not compute it (one exact square
+ * root per candidate pair less) and pbSimGetState returns NaN for it.  mode 1: always maintained (valid from the next step on).  Positions,
+ * velocities, radii, phases and absForce_r do not depend on the mode. */
+int pbSimSetForceSums(pbSim *sim, int mode);
 /* Lanes per bot in the per-step force kernel: 1 = throughput form (one bot per lane); 2, 4, 8, 16 =
  * that many adjacent lanes share a bot's neighbour list and add the terms in list order (batches
  * too small to fill the chip: the serial neighbour loop is the limit); 0 = automatic (default:
@@ -264,6 +274,8 @@ typedef struct pbSimConfig {
   int payload;
   int rng; /* 0 PB-RNG v1 (default), 1 cuRAND-compatible XORWOW */
   int offsets64; /* 1: the throughput sweep runs with 64-bit byte offsets (batches of 2^28 bots and more) */
+  int attraction_sums; /* 1: absForce_a is maintained (pbSimSetForceSums) */
+  int dead_sum_form;   /* 1: the force kernel that runs is a form without Sum|F_attr| */
 } pbSimConfig;
 int pbSimGetConfig(pbSim *sim, pbSimConfig *cfg);
 

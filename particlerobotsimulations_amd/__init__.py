@@ -197,6 +197,8 @@ class Sim:
         _capi.check(_capi.lib().pbSimGetState(self._h, *[_capi.np_ptr(out[k]) for k in
                                                          ("pos", "vel", "rad", "phase", "dead",
                                                           "absForce_a", "absForce_r")]), "pbSimGetState")
+        if not self.config()["attraction_sums"]:
+            out["absForce_a"] = None  # a dead value in this batch: not maintained (set_force_sums)
         return out
 
     @property
@@ -256,6 +258,11 @@ class Sim:
         arithmetic, opt-in, not bit-identical (include/particlebot_hip.h)."""
         _capi.check(_capi.lib().pbSimSetForceVariant(self._h, int(variant)))
 
+    def set_force_sums(self, mode):
+        """0 (default): absForce_a only when a member reads it (constrained_contraction); otherwise it
+        is a dead value, not computed, and get_state() returns NaN for it.  1: always maintained."""
+        _capi.check(_capi.lib().pbSimSetForceSums(self._h, int(mode)))
+
     def set_lanes_per_bot(self, lanes):
         _capi.check(_capi.lib().pbSimSetLanesPerBot(self._h, int(lanes)))
 
@@ -304,6 +311,8 @@ class Ensemble(Sim):
                                                                         ("pos", "vel", "rad", "phase", "dead",
                                                                          "absForce_a", "absForce_r")]),
                     "pbSimGetStateOf")
+        if not self.config()["attraction_sums"]:
+            out["absForce_a"] = None
         return out
 
     def centroids(self):

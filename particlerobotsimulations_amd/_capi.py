@@ -73,7 +73,8 @@ class pbSimStats(C.Structure):
 
 class pbSimConfig(C.Structure):
     _fields_ = [("force_variant", C.c_int), ("force_kind", C.c_int), ("lanes_per_bot", C.c_int),
-                ("resident", C.c_int), ("fast_math_ok", C.c_int), ("payload", C.c_int), ("rng", C.c_int), ("offsets64", C.c_int)]
+                ("resident", C.c_int), ("fast_math_ok", C.c_int), ("payload", C.c_int), ("rng", C.c_int), ("offsets64", C.c_int),
+                ("attraction_sums", C.c_int), ("dead_sum_form", C.c_int)]
 
 
 # every symbol include/particlebot_hip.h declares: name -> (restype, argtypes)
@@ -137,6 +138,7 @@ SYMBOLS = {
     "pbSimSetLanesPerBot": (_I, [_VP, _I]),
     "pbSimSetResident": (_I, [_VP, _I]),
     "pbSimGetConfig": (_I, [_VP, C.POINTER(pbSimConfig)]),
+    "pbSimSetForceSums": (_I, [_VP, _I]),
     "pbSimSetRng": (_I, [_VP, _I]),
     "pbSimGetRngStatesOf": (_I, [_VP, _U, _VP]),
     "pbSetRngKind": (_I, [_I]),

@@ -496,6 +496,114 @@ PB_DEV void pbPairEvalK(const PbContactK &P, const bool (&live)[K], float ax, fl
   }
 }
 
+// ---- the same pair term when Sum|F_attr| is a dead value ---------------------------------------
+// The reference keeps two magnitude sums per bot: absForce_r (contact terms) and absForce_a (all the
+// others).  Both are private scratch arrays (no getArray case, not in the dump); the only reader is
+// the next step's updateRad_light_wave, and it reads absForce_a solely under
+// `if (params.constrained_contraction)` (impl.cuh:167-169; 0 by default and in every shipped example).
+// With that switch off the attraction magnitudes -- a square root per candidate pair -- are dead
+// stores, and this form leaves them out: it returns the term (tx, ty) only.  A contact's squared
+// magnitude is handed to `pushRep` (same lanes, same order as the reference's `absforce_r +=`); the
+// caller takes the roots later, a handful per bot instead of one per trip (pbRepList below).
+// Every value that IS produced comes from exactly the operations of pbPairEvalK.
+struct PbPairXY {
+  float tx, ty;
+};
+
+template <bool FAST, class PushRep>
+PB_DEV PbPairXY pbPairEvalXY(const PbContactK &P, bool live, float ax, float ay, float avx, float avy, float ra,
+                             float bx, float by, float rb, float vbx, float vby, float attraction, float slope,
+                             PushRep pushRep) {
+  const float near1 = 0.0009f, near2 = 0.0019f, fmin_attr = 2.5f;
+  const float rx = bx - ax, ry = by - ay;
+  const float d2 = pbDot(rx, ry, rx, ry);
+  float dist, nx, ny;
+  if (FAST) {
+    dist = pbSqrtFast(d2);
+    pbDiv2Fast(rx, ry, dist, nx, ny);
+  } else {
+    dist = sqrtf(d2);
+    nx = rx / dist;
+    ny = ry / dist;
+  }
+  const float reach = ra + rb;
+  const bool contact = dist < reach;
+  const float gap = dist - reach;
+  const float g2 = gap * gap;
+  float tx, ty;
+  if (FAST) {
+    pbDiv2Fast(attraction * nx, attraction * ny, g2, tx, ty);
+  } else {
+    tx = attraction * nx / g2;
+    ty = attraction * ny / g2;
+  }
+  const unsigned long long mLive = __builtin_amdgcn_ballot_w64(live);
+  const unsigned long long mContact = __builtin_amdgcn_ballot_w64(contact);
+  if ((mLive & ~mContact & __builtin_amdgcn_ballot_w64(gap < near2)) != 0ull) {
+    const float band = gap < near1 ? fmin_attr : fmin_attr + slope * (gap - near1);
+    tx = gap < near2 ? band * nx : tx;
+    ty = gap < near2 ? band * ny : ty;
+  }
+  if ((mLive & mContact) != 0ull) {
+    // (lanes out of contact compute on their neighbour's velocity too; their result is not selected)
+    const float rvx = vbx - avx, rvy = vby - avy;
+    const float vn = pbDot(rvx, rvy, nx, ny);
+    const float tvx = rvx - vn * nx, tvy = rvy - vn * ny;
+    const float ks = -P.spring * (reach - dist);
+    float cx = ks * nx;
+    float cy = ks * ny;
+    cx += P.damping * rvx;
+    cy += P.damping * rvy;
+    cx += P.shear * tvx;
+    cy += P.shear * tvy;
+    pushRep(contact && live, pbDot(cx, cy, cx, cy));
+    tx = contact ? cx : tx;
+    ty = contact ? cy : ty;
+  }
+  PbPairXY r;
+  r.tx = tx;
+  r.ty = ty;
+  return r;
+}
+
+// A lane's pending contact magnitudes: squared values parked in LDS (one column per lane: entry k of
+// lane t at col[k * STRIDE], conflict-free), roots taken and added to Sum|F_rep| in list order by
+// flush().  push() is called by every lane of the wave inside the wave-uniform contact block: lanes
+// out of contact write to their next free entry without claiming it (no exec-mask juggling), which is
+// why a column has CAP + 1 entries.  A full column anywhere in the wave flushes the whole wave --
+// the sum's order does not change, only when the additions happen.
+template <bool FAST, int CAP, int STRIDE>
+struct PbRepList {
+  float *col;    // this lane's column
+  uint32_t off;  // next free entry, in floats from col (a multiple of STRIDE)
+  PB_DEV void init(float *column) {
+    col = column;
+    off = 0u;
+  }
+  PB_DEV void flush(float &fr) {
+    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < off) != 0ull; k += STRIDE) {
+      const float m2 = col[k];
+      float mag;
+      if (FAST) {
+        mag = pbSqrtFast(m2);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(k < off && pbTinyNonzero(m2)) != 0ull, 0)) {
+          asm volatile("; rare: a contact magnitude below 2^-48, full sqrtf" ::: "memory");
+          mag = sqrtf(m2);
+        }
+      } else {
+        mag = sqrtf(m2);
+      }
+      if (k < off) fr += mag;
+    }
+    off = 0u;
+  }
+  PB_DEV void push(bool mine, float m2, float &fr) {
+    col[off] = m2;
+    off += mine ? (uint32_t)STRIDE : 0u;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(off == (uint32_t)(CAP * STRIDE)) != 0ull, 0)) flush(fr);
+  }
+};
+
 PB_DEV void pbPairAdd(bool live, const PbPairTerm &t, PbForce &F) {
   if (live) {
     F.fx += t.tx;

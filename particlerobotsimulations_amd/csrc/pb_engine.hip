@@ -33,6 +33,7 @@
 //    of force variant 3.
 #include <algorithm>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -68,6 +69,9 @@ constexpr int TILE = PB_TILE;
 #endif
 #ifndef PB_THROUGHPUT_NB
 #define PB_THROUGHPUT_NB 1
+#endif
+#ifndef PB_REP_CAP
+#define PB_REP_CAP 8  // pending contact magnitudes per lane before the wave flushes (PbRepList)
 #endif
 // NB (template parameter of k_force): neighbours evaluated side by side per loop trip of the
 // one-lane-per-bot form.  1 is what ships.  2 (two independent dependency chains per wave, the
@@ -148,6 +152,27 @@ __device__ __forceinline__ void pbGroupSum(bool live, const PbPairTerm &t, PbFor
   F.fr = pbGroupLast<L>(ar);
 }
 
+// the same chain for one quantity / for the force components only (dead-sum form, pbPairEvalXY)
+template <int L>
+__device__ __forceinline__ void pbGroupSum1(float t, float &f) {
+  float a = f + t;
+#pragma unroll
+  for (int e = 1; e < L; e++) a = pbShr1(a) + t;
+  f = pbGroupLast<L>(a);
+}
+template <int L>
+__device__ __forceinline__ void pbGroupSumXY(bool live, const PbPairXY &t, PbForce &F) {
+  const float tx = live ? t.tx : 0.0f, ty = live ? t.ty : 0.0f;
+  float ax = F.fx + tx, ay = F.fy + ty;
+#pragma unroll
+  for (int e = 1; e < L; e++) {
+    ax = pbShr1(ax) + tx;
+    ay = pbShr1(ay) + ty;
+  }
+  F.fx = pbGroupLast<L>(ax);
+  F.fy = pbGroupLast<L>(ay);
+}
+
 // Flattened neighbour list of one bot (L > 1 form): plain scalars passed by value, so that they
 // stay in registers wherever the sweep is inlined (arrays or by-reference captures here ended up in
 // scratch memory with data-dependent indices).
@@ -210,11 +235,16 @@ struct PbSegCache {
 // flattened neighbour list at a time, then every lane of the group adds the L terms in list order
 // (ds_swizzle broadcasts inside the group), so the sums -- and their order -- are those of L == 1.
 // The serial chain per bot shrinks ~L/2-fold at ~2x the total VALU work.
-template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, bool CACHED, class PR, class VL, class OffT = uint32_t>
+// ASUM: maintain Sum|F_attr| (F.fa).  false (branch-free forms; the caller guarantees that no
+// simulation of the batch has constrained_contraction set, see pbPairEvalXY): F.fa is left alone;
+// in the throughput form the contact magnitudes go through the lane's LDS column repCol
+// (PbRepList, columns REPSTRIDE floats apart).
+template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, bool CACHED, class PR, class VL, class OffT = uint32_t,
+          bool ASUM = true, int REPSTRIDE = TILE>
 __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn,
                                         const uint32_t *__restrict__ cellS, uint32_t base, uint32_t s,
                                          uint32_t sub, const float4 &me, const float2 &v, float att1, PbForce &F,
-                                         PbSegCache &cache) {
+                                         PbSegCache &cache, float *repCol = nullptr) {
   const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
   const float slope0 = pbBandSlope(P.attraction);
   const float attraction0 = P.attraction;
@@ -275,10 +305,30 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
         const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
         const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
         const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
-        PbPairTerm t[1];
-        pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K, [&](int) { return w; }, t);
-        // the group's L terms join the running sums in list order
-        pbGroupSum<L>(live[0], t[0], F);
+        if (ASUM) {
+          PbPairTerm t[1];
+          pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K, [&](int) { return w; }, t);
+          // the group's L terms join the running sums in list order
+          pbGroupSum<L>(live[0], t[0], F);
+        } else {
+          // dead-sum form: no Sum|F_attr|; a contact's magnitude and the Sum|F_rep| chain only in the
+          // trips in which some lane of the wave is in contact
+          const PbPairXY t = pbPairEvalXY<FAST>(
+              CK, live[0], me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, w.x, w.y, A[0], K[0], [&](bool mine, float m2) {
+                float mag;
+                if (FAST) {
+                  mag = pbSqrtFast(m2);
+                  if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine && pbTinyNonzero(m2)) != 0ull, 0)) {
+                    asm volatile("; rare: a contact magnitude below 2^-48, full sqrtf" ::: "memory");
+                    mag = sqrtf(m2);
+                  }
+                } else {
+                  mag = sqrtf(m2);
+                }
+                pbGroupSum1<L>(mine ? mag : 0.0f, F.fr);
+              });
+          pbGroupSumXY<L>(live[0], t, F);
+        }
       }
     };
     if (__all(nseg == 1)) run(std::false_type{});
@@ -304,14 +354,36 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
     const OffT selfOff = (OffT)s * 16u;
     auto at = [&](OffT off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
     auto vat = [&](OffT off) __attribute__((always_inline)) { return *(const float2 *)(velBytes + (off >> 1)); };
-    auto one = [&](const float4 &q, const float2 &vq, OffT off) __attribute__((always_inline)) {
-      const bool live[1] = {off != selfOff};
+    PbRepList<FAST, PB_REP_CAP, REPSTRIDE> rep;
+    if (!ASUM) rep.init(repCol);
+    // (64-bit address arithmetic with a constant displacement: the displacement becomes the load's
+    //  immediate offset, so the look-ahead loads need no address instructions of their own)
+    auto atI = [&](OffT off, int imm) __attribute__((always_inline)) {
+      return *(const float4 *)(prBytes + (uint64_t)off + imm);
+    };
+    auto vatI = [&](OffT hoff, int imm) __attribute__((always_inline)) {
+      return *(const float2 *)(velBytes + (uint64_t)hoff + imm);
+    };
+    const OffT selfOff16 = selfOff + 16u;
+    auto one = [&](const float4 &q, const float2 &vq, bool isLive) __attribute__((always_inline)) {
+      const bool live[1] = {isLive};
       const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
       const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
       const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
-      PbPairTerm t[1];
-      pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K, [&](int) { return vq; }, t);
-      pbPairAdd(live[0], t[0], F);
+      if (ASUM) {
+        PbPairTerm t[1];
+        pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K, [&](int) { return vq; }, t);
+        pbPairAdd(live[0], t[0], F);
+      } else {
+        const PbPairXY t = pbPairEvalXY<FAST>(CK, live[0], me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, vq.x, vq.y, A[0],
+                                              K[0], [&](bool mine, float m2) { rep.push(mine, m2, F.fr); });
+        if (live[0]) {
+          // (a real exec-masked block -- two scalar instructions -- instead of two selects per trip)
+          asm volatile("");
+          F.fx += t.tx;
+          F.fy += t.ty;
+        }
+      }
     };
     // byte offsets [lo, hi) of segment si; empty beyond the last one and for the second range of a
     // row away from the x-wrap
@@ -344,19 +416,25 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
       vA = vat(loA);
       bounds(si + 2 * stride, loB, hiB);   // bounds of the one after
       if (lo < end) {
-        OffT off = lo;
+        // two neighbours per turn of the loop: `off` is the even one's byte offset, hoff = off / 2 the
+        // offset of its velocity
+        OffT off = lo, hoff = lo >> 1;
+        const OffT endm = end - 16u;
         for (;;) {
-          const float4 q1 = at(off + 16u);
-          const float2 v1 = vat(off + 16u);
-          one(q0, v0, off);
-          if ((off += 16u) >= end) break;
-          q0 = at(off + 16u);
-          v0 = vat(off + 16u);
-          one(q1, v1, off);
-          if ((off += 16u) >= end) break;
+          const float4 q1 = atI(off, 16);
+          const float2 v1 = vatI(hoff, 8);
+          one(q0, v0, off != selfOff);
+          if (off >= endm) break;
+          off += 32u;
+          hoff += 16u;
+          q0 = atI(off, 0);
+          v0 = vatI(hoff, 0);
+          one(q1, v1, off != selfOff16);
+          if (off >= end) break;
         }
       }
     }
+    if (!ASUM) rep.flush(F.fr);
     return;
   }
   if (FLAT && NB == 2) {
@@ -489,12 +567,13 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
   }
 }
 
-template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, class OffT, class PR, class VL>
+template <bool PAYLOAD, bool FLAT, bool FAST, int L, int NB, class OffT, bool ASUM = true, class PR, class VL>
 __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn, const uint32_t *__restrict__ cellS,
                                         uint32_t base, uint32_t s, uint32_t sub, const float4 &me, const float2 &v,
-                                        float att1, PbForce &F) {
+                                        float att1, PbForce &F, float *repCol = nullptr) {
   PbSegCache none;
-  pbSweepC<PAYLOAD, FLAT, FAST, L, NB, false, PR, VL, OffT>(P, prIn, velIn, cellS, base, s, sub, me, v, att1, F, none);
+  pbSweepC<PAYLOAD, FLAT, FAST, L, NB, false, PR, VL, OffT, ASUM>(P, prIn, velIn, cellS, base, s, sub, me, v, att1, F,
+                                                                  none, repCol);
 }
 
 // Forces + kick of step n (impl.cuh:657-831); with FUSE also radius + integration of step n+1.
@@ -503,7 +582,9 @@ __device__ __forceinline__ void pbSweep(const PbDevParams &P, PR prIn, VL velIn,
 // FASTOK: the simulation passed pbFastMathAllowed, so waves whose lanes all pass
 // pbLaneFastMathOk may use the exact fast sqrt/division forms.
 // BIG: 64-bit byte offsets in the neighbour sweep (batches of 2^28 bots and more, throughput form only).
-template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB, bool BIG = false>
+// ASUM: maintain absForce_a.  false (throughput form, batches without constrained contraction):
+// the attraction magnitudes are dead values and are neither computed nor stored (pbPairEvalXY).
+template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB, bool BIG = false, bool ASUM = true>
 __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) void k_force(const PbDevParams *__restrict__ params,
                                                 const float4 *__restrict__ prIn, const float2 *__restrict__ velIn,
                                                 float4 *__restrict__ prOut, float2 *__restrict__ velOut,
@@ -541,10 +622,14 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
 
   // wave-uniform choice: the fast exact forms need every lane's coordinates away from zero
   using OffT = typename std::conditional<BIG, uint64_t, uint32_t>::type;
+  static_assert(ASUM || (FLAT && NB == 1), "the dead-sum form exists for the branch-free sweeps only");
+  constexpr bool REPLIST = !ASUM && L == 1;  // (L > 1: magnitudes are rooted inside the contact block)
+  __shared__ float repLds[REPLIST ? (PB_REP_CAP + 1) * TILE : 1];
+  float *const repCol = &repLds[REPLIST ? threadIdx.x : 0];
   if (FLAT && FASTOK && __all(pbLaneFastMathOk(me.x, me.y)))
-    pbSweep<PAYLOAD, FLAT, true, L, NB, OffT>(P, prIn, velIn, cellS, 0u, s, sub, me, v, att1, F);
+    pbSweep<PAYLOAD, FLAT, true, L, NB, OffT, ASUM>(P, prIn, velIn, cellS, 0u, s, sub, me, v, att1, F, repCol);
   else
-    pbSweep<PAYLOAD, FLAT, false, L, NB, OffT>(P, prIn, velIn, cellS, 0u, s, sub, me, v, att1, F);
+    pbSweep<PAYLOAD, FLAT, false, L, NB, OffT, ASUM>(P, prIn, velIn, cellS, 0u, s, sub, me, v, att1, F, repCol);
   pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
   pbFrictionAndKick(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
 
@@ -556,7 +641,7 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
   if (sub == 0) {  // the L lanes of a group hold identical results
     prOut[s] = out;
     velOut[s] = v;
-    absA[s] = F.fa;
+    if (ASUM) absA[s] = F.fa;
     absR[s] = F.fr;
   }
 #ifdef PB_TIMELINE
@@ -803,7 +888,7 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
 // cell table -> neighbours); here those become LDS reads.  The host launches it for the stretch of
 // steps up to the next re-sort / phase update / caller boundary (stepMany).  Same device functions,
 // same order of operations as k_state + k_force: bit-identical results.
-template <bool PAYLOAD, bool FASTOK, int L>
+template <bool PAYLOAD, bool FASTOK, int L, bool ASUM = true>
 __global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict__ params, float4 *__restrict__ pr,
                                                    float2 *__restrict__ vel, const float *__restrict__ phase,
                                                    const int *__restrict__ dead, float *__restrict__ absA,
@@ -813,6 +898,9 @@ __global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict
   constexpr int CAP = 1024 / L;
   __shared__ float4 sPr[2][CAP + 1];  // +1: the sweep prefetches one slot past a range
   __shared__ float2 sVel[2][CAP + 1];
+  constexpr bool REPLIST = !ASUM && L == 1;
+  __shared__ float repLds[REPLIST ? (PB_REP_CAP + 1) * 1024 : 1];
+  float *const repCol = &repLds[REPLIST ? threadIdx.x : 0];
   const PbDevParams &P = params[blockIdx.x];
   const uint32_t l = threadIdx.x / L, sub = threadIdx.x % L;
   const bool active = l < n;
@@ -852,10 +940,14 @@ __global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict
       F.fr = 0.0f * fr;  // impl.cuh:688
       const float4 *prIn = sPr[cur];
       const float2 *velIn = sVel[cur];
+      using PR = const float4 *;
+      using VL = const float2 *;
       if (FASTOK && __all(pbLaneFastMathOk(me.x, me.y)))
-        pbSweepC<PAYLOAD, true, true, L, 1, (L > 1)>(P, prIn, velIn, cellS, base, l, sub, me, v, att1, F, segCache);
+        pbSweepC<PAYLOAD, true, true, L, 1, (L > 1), PR, VL, uint32_t, ASUM, 1024>(P, prIn, velIn, cellS, base, l, sub, me,
+                                                                                 v, att1, F, segCache, repCol);
       else
-        pbSweepC<PAYLOAD, true, false, L, 1, (L > 1)>(P, prIn, velIn, cellS, base, l, sub, me, v, att1, F, segCache);
+        pbSweepC<PAYLOAD, true, false, L, 1, (L > 1), PR, VL, uint32_t, ASUM, 1024>(P, prIn, velIn, cellS, base, l, sub,
+                                                                                  me, v, att1, F, segCache, repCol);
       pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
       pbFrictionAndKick(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
       fa = F.fa;
@@ -876,7 +968,7 @@ __global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict
   if (active && sub == 0) {
     pr[s] = me;
     vel[s] = v;
-    absA[s] = fa;
+    if (ASUM) absA[s] = fa;
     absR[s] = fr;
   }
 }
@@ -1331,6 +1423,8 @@ struct pbSim {
   bool debugForceBig = false;  // PB_DEBUG_FORCE_BIG under PB_ALLOW_ENV_OVERRIDES=1
   unsigned debugLdsBytes = 0;  // PB_DEBUG_LDS_BYTES under PB_ALLOW_ENV_OVERRIDES=1 (tools/occupancy_sweep.py --lds)
   int rng = 0;          // phase noise: 0 PB-RNG v1 (counter based), 1 cuRAND-compatible XORWOW (pb_xorwow.hpp)
+  int forceSums = 0;    // 0: Sum|F_attr| only when a member reads it (constrained_contraction), 1: always
+  bool anyConstrained = false;  // some member has constrained_contraction != 0
   pbSimStats stats{};
 };
 
@@ -1347,14 +1441,14 @@ inline dim3 gridOf(const pbSim *S) { return dim3(cdiv(S->n, TILE), S->nsims); }
 // several batches from several threads must not have to remember that
 inline void useDevice(const pbSim *S) { (void)hipSetDevice(S->device); }
 
-template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB, bool BIG = false>
+template <bool FUSE, bool PAYLOAD, bool FLAT, bool FASTOK, int L, int NB, bool BIG = false, bool ASUM = true>
 void launchForceT(pbSim *S, int c, int o, float dt, float tNext, int doRadiusNext) {
   const uint32_t tiles = cdiv(S->n, TILE / L);
   // XCD-aware order only pays when a simulation spans many tiles
   const uint32_t perXcd = (L == 1 && tiles >= 64u) ? cdiv(tiles, 8u) : 0u;
   const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
   // (debugLdsBytes: an occupancy experiment -- unused dynamic LDS that only limits workgroups per CU)
-  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK, L, NB, BIG>), grid, dim3(TILE), S->debugLdsBytes, S->stream, S->dP, S->pr[c],
+  hipLaunchKernelGGL((k_force<FUSE, PAYLOAD, FLAT, FASTOK, L, NB, BIG, ASUM>), grid, dim3(TILE), S->debugLdsBytes, S->stream, S->dP, S->pr[c],
                      S->vel[c], S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c],
                      S->cellS, S->n, dt, tNext, doRadiusNext, perXcd);
 }
@@ -1366,10 +1460,14 @@ struct PbForcePlan {
   bool stream;
   int kind;
   int form;  // lanes per bot (1 = throughput form)
+  bool asum; // the launch maintains absForce_a (false: dead-sum form of the throughput sweep)
 };
 
+// absForce_a has a reader (impl.cuh:167-169) or the caller asked for it (pbSimSetForceSums)
+inline bool attractionSumsKept(const pbSim *S) { return S->forceSums != 0 || S->anyConstrained; }
+
 PbForcePlan forcePlan(const pbSim *S) {
-  PbForcePlan p{false, 0, 1};
+  PbForcePlan p{false, 0, 1, true};
   if (S->variant == 3 && S->total < (1u << 28) - 4u &&  // (32-bit byte offsets into posrad)
       (S->lanesPerBot == 1 || (S->lanesPerBot == 0 && S->total > 131072u))) {
     // streamlined arithmetic: throughput form only (smaller batches use the exact forms below)
@@ -1391,6 +1489,8 @@ PbForcePlan forcePlan(const pbSim *S) {
     else if (want == 8 || (want == 0 && S->total <= 49152u)) p.form = 8;
     else if (want == 4 || (want == 0 && S->total <= 131072u)) p.form = 4;
     else if (want == 2) p.form = 2;
+    // the dead-sum forms exist for the branch-free kernels
+    if (PB_THROUGHPUT_NB == 1 && !attractionSumsKept(S)) p.asum = false;
   }
   return p;
 }
@@ -1418,11 +1518,19 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
   const bool big = S->total >= (1u << 28) - 8u || S->debugForceBig;
 #define PB_CASE(F, PL, K, FL, FA)                                                                        \
   if (fuse == F && payload == PL && kind == K) {                                                         \
+    if (FL && !plan.asum) {                                                                                        \
+      if (form == 16) return launchForceT<F, PL, FL, FA, (FL ? 16 : 1), 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext); \
+      if (form == 8) return launchForceT<F, PL, FL, FA, (FL ? 8 : 1), 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext); \
+      if (form == 4) return launchForceT<F, PL, FL, FA, (FL ? 4 : 1), 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext); \
+      if (form == 2) return launchForceT<F, PL, FL, FA, (FL ? 2 : 1), 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext); \
+    }                                                                                                              \
     if (FL && form == 16) return launchForceT<F, PL, FL, FA, (FL ? 16 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 8) return launchForceT<F, PL, FL, FA, (FL ? 8 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 4) return launchForceT<F, PL, FL, FA, (FL ? 4 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 2) return launchForceT<F, PL, FL, FA, (FL ? 2 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
+    if (FL && big && !plan.asum) return launchForceT<F, PL, FL, FA, 1, 1, FL, !FL>(S, c, o, dt, tNext, doRadiusNext);                \
     if (FL && big) return launchForceT<F, PL, FL, FA, 1, 1, FL>(S, c, o, dt, tNext, doRadiusNext);                                   \
+    if (FL && !plan.asum) return launchForceT<F, PL, FL, FA, 1, 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext);                    \
     return launchForceT<F, PL, FL, FA, 1, (FL ? PB_THROUGHPUT_NB : 1)>(S, c, o, dt, tNext, doRadiusNext);                            \
   }
   PB_CASE(true, true, 0, false, false)
@@ -1462,13 +1570,13 @@ bool residentWanted(const pbSim *S) {
   return residentUs < perStepUs;
 }
 
-template <bool PAYLOAD, bool FASTOK>
+template <bool PAYLOAD, bool FASTOK, bool ASUM>
 void launchResidentT(pbSim *S, float dt, float t0, int m, int lightWave) {
   const int c = S->cur;
   const int L = residentLanes(S->n);
   const dim3 grid(S->nsims), block(cdiv(S->n * (uint32_t)L, 64u) * 64u);
 #define PB_RES(LL)                                                                                      \
-  hipLaunchKernelGGL((k_resident<PAYLOAD, FASTOK, LL>), grid, block, 0, S->stream, S->dP, S->pr[c], S->vel[c], \
+  hipLaunchKernelGGL((k_resident<PAYLOAD, FASTOK, LL, ASUM>), grid, block, 0, S->stream, S->dP, S->pr[c], S->vel[c], \
                      S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c], S->cellS, S->n, dt, t0, m,   \
                      lightWave)
   if (L == 8) PB_RES(8);
@@ -1480,13 +1588,20 @@ void launchResidentT(pbSim *S, float dt, float t0, int m, int lightWave) {
 
 void launchResident(pbSim *S, float dt, float t0, int m, int lightWave) {
   const bool fast = S->variant >= 2 && S->fastOk;
+  const bool asum = attractionSumsKept(S);
+#define PB_RESL(PL, FA)                                                   \
+  do {                                                                    \
+    if (asum) launchResidentT<PL, FA, true>(S, dt, t0, m, lightWave);     \
+    else launchResidentT<PL, FA, false>(S, dt, t0, m, lightWave);         \
+  } while (0)
   if (S->payload) {
-    if (fast) launchResidentT<true, true>(S, dt, t0, m, lightWave);
-    else launchResidentT<true, false>(S, dt, t0, m, lightWave);
+    if (fast) PB_RESL(true, true);
+    else PB_RESL(true, false);
   } else {
-    if (fast) launchResidentT<false, true>(S, dt, t0, m, lightWave);
-    else launchResidentT<false, false>(S, dt, t0, m, lightWave);
+    if (fast) PB_RESL(false, true);
+    else PB_RESL(false, false);
   }
+#undef PB_RESL
 }
 
 int resort(pbSim *S) {
@@ -1731,6 +1846,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   for (int k = 0; k < nsims; k++) {
     pbFlattenParams(S->hP[k], params[k], wallHalf);
     S->fastOk = S->fastOk && pbFastMathAllowed(S->hP[k]);
+    S->anyConstrained = S->anyConstrained || S->hP[k].constrained_contraction != 0u;
   }
   // A/B switches for tools/ab_bench.py: honoured only under PB_ALLOW_ENV_OVERRIDES=1 and through the
   // same range checks as the setters, so a stray variable cannot silently change what a caller runs
@@ -1739,6 +1855,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     if (const char *v = getenv("PB_FORCE_VARIANT")) rc |= pbSimSetForceVariant(S, atoi(v));
     if (const char *v = getenv("PB_LANES_PER_BOT")) rc |= pbSimSetLanesPerBot(S, atoi(v));
     if (const char *v = getenv("PB_RESIDENT")) rc |= pbSimSetResident(S, atoi(v));
+    if (const char *v = getenv("PB_FORCE_SUMS")) rc |= pbSimSetForceSums(S, atoi(v));
     if (const char *v = getenv("PB_DEBUG_LDS_BYTES")) S->debugLdsBytes = (unsigned)std::min(atol(v), 65536L);
     if (const char *v = getenv("PB_DEBUG_FORCE_BIG")) S->debugForceBig = atoi(v) != 0;
     if (rc != PB_OK) {
@@ -1868,9 +1985,12 @@ int pbSimGetStateOf(pbSim *S, unsigned sim, float *pos, float *vel, float *rad, 
   if (rad) PB_TRY(hipMemcpyAsync(rad, st + 16 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
   if (phase) PB_TRY(hipMemcpyAsync(phase, st + 20 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
   if (dead) PB_TRY(hipMemcpyAsync(dead, st + 24 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
-  if (absForce_a) PB_TRY(hipMemcpyAsync(absForce_a, st + 28 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
+  const bool haveA = attractionSumsKept(S);
+  if (absForce_a && haveA) PB_TRY(hipMemcpyAsync(absForce_a, st + 28 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
   if (absForce_r) PB_TRY(hipMemcpyAsync(absForce_r, st + 32 * n, 4 * n, hipMemcpyDeviceToHost, S->stream));
   PB_TRY(hipStreamSynchronize(S->stream));
+  // not maintained (no reader, see pbSimSetForceSums): say so instead of handing out stale numbers
+  if (absForce_a && !haveA) std::fill(absForce_a, absForce_a + n, std::numeric_limits<float>::quiet_NaN());
   return PB_OK;
 }
 
@@ -2082,6 +2202,12 @@ int pbSimSetForceVariant(pbSim *S, int variant) {
   return PB_OK;
 }
 
+int pbSimSetForceSums(pbSim *S, int mode) {
+  if (!S || mode < 0 || mode > 1) return PB_ERR_ARG;
+  S->forceSums = mode;
+  return PB_OK;
+}
+
 int pbSimSetLanesPerBot(pbSim *S, int lanes) {
   if (!S || !(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16)) return PB_ERR_ARG;
   S->lanesPerBot = lanes;
@@ -2132,6 +2258,8 @@ int pbSimGetConfig(pbSim *S, pbSimConfig *cfg) {
   cfg->payload = S->payload ? 1 : 0;
   cfg->rng = S->rng;
   cfg->offsets64 = (p.form == 1 && p.kind >= 1 && !p.stream && (S->total >= (1u << 28) - 8u || S->debugForceBig)) ? 1 : 0;
+  cfg->attraction_sums = attractionSumsKept(S) ? 1 : 0;
+  cfg->dead_sum_form = (cfg->resident ? !attractionSumsKept(S) : (!p.stream && !p.asum)) ? 1 : 0;
   return PB_OK;
 }
 

@@ -31,6 +31,11 @@ def bits(a):
 
 
 def assert_bit_equal(a, b, what=""):
+    if a is None:
+        # absForce_a of a batch in which nothing reads it (pbSimSetForceSums mode 0): not maintained.
+        # tests/test_gpu_dead_sum.py compares it in mode 1 and everything else in both modes.
+        assert "absForce_a" in what, what
+        return
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
     assert a.shape == b.shape, (what, a.shape, b.shape)

@@ -81,6 +81,9 @@ def main():
             bad = {}
             for kk in soak_fuzz.KEYS:
                 a, b = st[kk], ref[kk]
+                if a is None:
+                    bad[kk] = 0
+                    continue
                 both = np.isnan(a) & np.isnan(b)
                 bad[kk] = int(((a.view(np.uint32) != b.view(np.uint32)) & ~both).sum())
             line.append(f"{f}: {bad if any(bad.values()) else 'ok'}")
@@ -91,6 +94,8 @@ def main():
             f, st = worst
             for kk in ("vel", "absForce_a", "pos"):
                 a, b = st[kk], ref[kk]
+                if a is None:
+                    continue
                 both = np.isnan(a) & np.isnan(b)
                 d = (a.view(np.uint32) != b.view(np.uint32)) & ~both
                 idx = np.flatnonzero(d.reshape(len(a), -1).any(axis=1))

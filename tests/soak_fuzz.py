@@ -72,6 +72,8 @@ def one(pb, orc, trial, seed0):
         st = gsim.get_state()
         for key in KEYS:
             a, b = st[key], osim.get(key)
+            if a is None:  # absForce_a without a reader: not maintained
+                continue
             nan = np.isnan(a) & np.isnan(b)
             assert_bit_equal(np.where(nan, 0, a).astype(a.dtype), np.where(nan, 0, b).astype(b.dtype),
                              f"trial {trial} (n={n}, form={form}, rng={kind}, payload={payload}) step {k}: {key}")

@@ -276,6 +276,8 @@ def test_force_kernel_variants_match_oracle(pb, orc, variant):
     st = gsim.get_state()
     for key in STATE_KEYS:
         a, b = st[key], osim.get(key)
+        if a is None:  # absForce_a: no reader in this batch, not maintained (tests/test_gpu_dead_sum.py)
+            continue
         both_nan = np.isnan(a) & np.isnan(b)  # NaN payloads are not compared
         assert_bit_equal(np.where(both_nan, 0, a).astype(a.dtype), np.where(both_nan, 0, b).astype(b.dtype),
                          f"variant {variant}: {key}")

@@ -90,7 +90,7 @@ def test_windows_within_1e5_relative(pb, orc, case):
         com_g = st["pos"].astype(np.float64).mean(0)
         com_o = osim.get("pos").astype(np.float64).mean(0)
         assert np.linalg.norm(com_g - com_o) <= RTOL * np.linalg.norm(com_o), (case, start)
-        assert np.isfinite(st["vel"]).all() and np.isfinite(st["absForce_a"]).all()
+        assert np.isfinite(st["vel"]).all() and np.isfinite(st["absForce_r"]).all()
         assert np.quantile(np.abs(st["rad"] - osim.get("rad")) / osim.get("rad"), 0.99) <= RTOL
         resync(gsim, osim)
         step = start + WINDOW

@@ -5,6 +5,7 @@ state; rounds of K steps alternate between them; device time comes from HIP even
 simulation's stream.  Also checks that all variants end bit-identical.
 
   python tools/ab_bench.py --variants 0,1 --bots 1000000 --rounds 6 --steps 200 --skip 100
+  python tools/ab_bench.py --variants 2s1,2 ...     (2s1: variant 2 with both magnitude sums kept)
 """
 import argparse
 import os
@@ -43,7 +44,10 @@ def main():
     for v in variants:
         sp, keep = bench.workload_params(n, seed=1)
         s = pb.Sim(sp, wall_half=240.0, keepalive=keep)
-        s.set_force_variant(int(v))
+        # "2" = force variant 2; "2s1" = variant 2 with both magnitude sums kept (pbSimSetForceSums 1)
+        s.set_force_variant(int(v.split("s")[0]))
+        if "s" in v:
+            s.set_force_sums(int(v.split("s")[1]))
         s.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
                     phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
         s.step(args.skip)
@@ -57,7 +61,7 @@ def main():
     for v in variants:
         st = sims[v].get_state()
         same = all(np.array_equal(st[k].view(np.uint32), ref[k].view(np.uint32))
-                   for k in ("pos", "vel", "rad", "absForce_a", "absForce_r"))
+                   for k in ("pos", "vel", "rad", "absForce_a", "absForce_r") if st[k] is not None and ref[k] is not None)
         dev = np.abs(st["pos"].astype(np.float64) - ref["pos"]).max()
         t = np.array(times[v])
         print(f"variant {v}: us/step per round {np.round(t, 1).tolist()}  median {np.median(t):.1f}  min {t.min():.1f}  "
