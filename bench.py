@@ -214,6 +214,22 @@ def streamlined_leg(pb, n, pitch, steps, warmup):
                     "kernel."}
 
 
+def both_sums_leg(pb, n, pitch, steps, warmup):
+    """The same workload with BOTH magnitude sums maintained (pbSimSetForceSums mode 1: what a batch with
+    constrained_contraction set runs), so the line shows what leaving out the dead Sum|F_attr| is worth.
+    Positions, velocities, radii, phases and absForce_r are bit-identical in the two modes
+    (tests/test_gpu_dead_sum.py)."""
+    sim = make_sim(pb, n, pitch, seed=1)
+    sim.set_force_sums(1)
+    sim.step(warmup)
+    done, ms = sim.step_timed(steps)
+    cfg = sim.config()
+    sim.close()
+    return {"value": n * done / (ms * 1e-3), "unit": "particle-steps/s (device time)", "steps": done,
+            "us_per_step": ms * 1e3 / max(done, 1), "attraction_sums": cfg["attraction_sums"],
+            "dead_sum_form": cfg["dead_sum_form"]}
+
+
 class DevicePrewarm:
     """The chip ramps its clocks over the first ~100 ms of load and drops them again when idle
     (measured: the first 20 steps after an idle spell run at 137 us, after 50 ms of the same kind of
@@ -570,6 +586,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-survey-literal", action="store_true")
     ap.add_argument("--no-streamlined", action="store_true")
+    ap.add_argument("--no-both-sums", action="store_true")
     ap.add_argument("--no-large-arena", action="store_true")
     ap.add_argument("--no-clock", action="store_true")
     ap.add_argument("--no-blob", action="store_true")
@@ -686,6 +703,10 @@ def main():
                        "bots_per_gpu": n, "dt": 0.01, "sort_interval": 180.0,
                        "force_variant": cfg["force_variant"], "force_kind": cfg["force_kind"],
                        "lanes_per_bot": cfg["lanes_per_bot"], "resident": cfg["resident"],
+                       "attraction_sums": cfg["attraction_sums"], "dead_sum_form": cfg["dead_sum_form"],
+                       "force_sums_note": "constrained_contraction = 0 (the reference's default): absForce_a has no "
+                                          "reader and is not computed (pbSimSetForceSums mode 0); every array the "
+                                          "reference reads or writes out is bit-identical either way",
                        "parallelism": "single arena" if world == 1 else f"{world} independent arenas, one per GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -703,7 +724,7 @@ def main():
                          "note": "achieved/peak/frac are the HBM accounting SURVEY 8(d) prescribes (64 algorithmic "
                                  "bytes per particle-step over the kernel's launch time); the kernel is VALU-issue "
                                  "bound, not HBM bound (~50 neighbour pairs per bot, each with 4 IEEE divisions and 2 "
-                                 "IEEE square roots, DESIGN.md section 5): `valu` prices its instruction stream at the "
+                                 "IEEE square roots -- one fewer since Sum|F_attr| is only kept when something reads it --, DESIGN.md section 5): `valu` prices its instruction stream at the "
                                  "datasheet issue rate at the measured shader clock and at tools/valu_rate's rates; "
                                  "`traffic` (PMC) ~ algorithmic bytes, i.e. no wasted re-reads"},
             "device_ms_timed_region": dev_ms,
@@ -719,6 +740,8 @@ def main():
             out["random_blob"] = blob_leg(pb, n, min(args.steps, 600), args.warmup)
         if world == 1 and not args.no_survey_literal:
             out["survey_literal_lattice"] = survey_literal(pb, n, args.steps, args.warmup)
+        if world == 1 and not args.no_both_sums:
+            out["both_sums"] = both_sums_leg(pb, n, args.pitch, min(args.steps, 400), max(args.warmup, 100))
         if world == 1 and not args.no_streamlined:
             out["streamlined"] = streamlined_leg(pb, n, args.pitch, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:

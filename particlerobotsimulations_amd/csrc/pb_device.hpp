@@ -271,6 +271,50 @@ PB_DEV void pbDiv2Fast(float a, float b, float d, float &qa, float &qb) {
   qb = __builtin_fmaf(t, r, q);
 }
 
+// Distance and unit vector of a pair from ONE transcendental (v_rsq_f32) instead of v_sqrt_f32 + v_rcp_f32:
+//   s    = v_rsq_f32(d2), clamped to FLT_MAX (d2 == 0: coincident bots must still get dist = 0, not NaN, to
+//          land in the reference's contact branch)
+//   dist = two Newton steps on y = d2*s with h = s/2           == sqrtf(d2)
+//   r    = one Newton step on s against dist                   (the reciprocal pbDiv2Fast would refine from v_rcp_f32)
+//   n    = (rx, ry) * r with pbDiv2Fast's two residual corrections == (rx/dist, ry/dist)
+// tools/rsq_form_test.hip checks this on the GPU EXHAUSTIVELY: the square root for every float that is 0 or in
+// [2^-96, FLT_MAX) (1 879 048 193 values, 0 differ from sqrtf), and the quotient for every d2 in [1, 4) -- all 2^24
+// mantissa x exponent-parity cases -- against every numerator mantissa (2^47 divisions, compared with the
+// compiler's IEEE a/dist; scaling d2 by 4^k and a numerator by 2^m scales every intermediate exactly inside the
+// domain below).  Result (profiles/r2_rsq_form_exhaustive.txt): r equals the v_rcp_f32-seeded reciprocal for
+// every d2 except the two whose root has an all-ones mantissa (dist = 2 - ulp: the true 1/dist lies 2^-49 above
+// a rounding tie, a Newton step from s = 2^k lands exactly ON the tie and rounds to even); only there do
+// quotients differ (2 of 2^47).  In those cases e = 1 - dist*s is exactly 2^-24, which sends the wave to the
+// v_rcp_f32 form (0 mismatches over the same 2^47).  Domain: as pbSqrtFast / pbDiv2Fast (d2 == 0 or >= 2^-88
+// in the kernel; numerators +0 or >= 2^-100).
+PB_DEV void pbDistUnitFast(float rx, float ry, float d2, float &dist, float &nx, float &ny) {
+  const float s = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(d2), 0.0f, 0x1.fffffep127f);
+  const float h = 0.5f * s;
+  float y = d2 * s;
+  float e = __builtin_fmaf(-y, y, d2);
+  y = __builtin_fmaf(e, h, y);
+  e = __builtin_fmaf(-y, y, d2);
+  y = __builtin_fmaf(e, h, y);
+  dist = y;
+  const float er = __builtin_fmaf(-y, s, 1.0f);
+  float r = __builtin_fmaf(er, s, s);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(er == 0x1p-24f) != 0ull, 0)) {
+    asm volatile("; rare: reciprocal of an all-ones root, v_rcp_f32 form" ::: "memory");
+    const float c = __builtin_amdgcn_rcpf(y);
+    r = __builtin_fmaf(__builtin_fmaf(-y, c, 1.0f), c, c);
+  }
+  float q = rx * r;
+  float t = __builtin_fmaf(-y, q, rx);
+  q = __builtin_fmaf(t, r, q);
+  t = __builtin_fmaf(-y, q, rx);
+  nx = __builtin_fmaf(t, r, q);
+  q = ry * r;
+  t = __builtin_fmaf(-y, q, ry);
+  q = __builtin_fmaf(t, r, q);
+  t = __builtin_fmaf(-y, q, ry);
+  ny = __builtin_fmaf(t, r, q);
+}
+
 // x is a non-negative float (or NaN): true when it is nonzero but below 2^-96, the only
 // non-negative inputs for which pbSqrtFast may differ from sqrtf
 PB_DEV bool pbTinyNonzero(float x) { return __float_as_uint(x) - 1u < 0x0F800000u - 1u; }
@@ -407,8 +451,7 @@ PB_DEV void pbPairEvalK(const PbContactK &P, const bool (&live)[K], float ax, fl
     const float rx = bx[k] - ax, ry = by[k] - ay;
     const float d2 = pbDot(rx, ry, rx, ry);
     if (FAST) {
-      dist[k] = pbSqrtFast(d2);
-      pbDiv2Fast(rx, ry, dist[k], nx[k], ny[k]);
+      pbDistUnitFast(rx, ry, d2, dist[k], nx[k], ny[k]);
     } else {
       dist[k] = sqrtf(d2);
       nx[k] = rx / dist[k];
@@ -519,8 +562,7 @@ PB_DEV PbPairXY pbPairEvalXY(const PbContactK &P, bool live, float ax, float ay,
   const float d2 = pbDot(rx, ry, rx, ry);
   float dist, nx, ny;
   if (FAST) {
-    dist = pbSqrtFast(d2);
-    pbDiv2Fast(rx, ry, dist, nx, ny);
+    pbDistUnitFast(rx, ry, d2, dist, nx, ny);
   } else {
     dist = sqrtf(d2);
     nx = rx / dist;
@@ -537,28 +579,33 @@ PB_DEV PbPairXY pbPairEvalXY(const PbContactK &P, bool live, float ax, float ay,
     tx = attraction * nx / g2;
     ty = attraction * ny / g2;
   }
-  const unsigned long long mLive = __builtin_amdgcn_ballot_w64(live);
-  const unsigned long long mContact = __builtin_amdgcn_ballot_w64(contact);
-  if ((mLive & ~mContact & __builtin_amdgcn_ballot_w64(gap < near2)) != 0ull) {
-    const float band = gap < near1 ? fmin_attr : fmin_attr + slope * (gap - near1);
-    tx = gap < near2 ? band * nx : tx;
-    ty = gap < near2 ? band * ny : ty;
-  }
-  if ((mLive & mContact) != 0ull) {
-    // (lanes out of contact compute on their neighbour's velocity too; their result is not selected)
-    const float rvx = vbx - avx, rvy = vby - avy;
-    const float vn = pbDot(rvx, rvy, nx, ny);
-    const float tvx = rvx - vn * nx, tvy = rvy - vn * ny;
-    const float ks = -P.spring * (reach - dist);
-    float cx = ks * nx;
-    float cy = ks * ny;
-    cx += P.damping * rvx;
-    cy += P.damping * rvy;
-    cx += P.shear * tvx;
-    cy += P.shear * tvy;
-    pushRep(contact && live, pbDot(cx, cy, cx, cy));
-    tx = contact ? cx : tx;
-    ty = contact ? cy : ty;
+  // One comparison decides the common case: gap < near2 covers the two near bands AND contact (a contact is
+  // gap < 0: for finite floats dist < reach <=> dist - reach < 0, and NaN fails both).  Only a trip in which
+  // some live lane passes it works out which lanes are which.
+  const unsigned long long mNear = __builtin_amdgcn_ballot_w64(live) & __builtin_amdgcn_ballot_w64(gap < near2);
+  if (mNear != 0ull) {
+    const unsigned long long mContact = __builtin_amdgcn_ballot_w64(contact);
+    if ((mNear & ~mContact) != 0ull) {
+      const float band = gap < near1 ? fmin_attr : fmin_attr + slope * (gap - near1);
+      tx = gap < near2 ? band * nx : tx;
+      ty = gap < near2 ? band * ny : ty;
+    }
+    if ((mNear & mContact) != 0ull) {
+      // (lanes out of contact compute on their neighbour's velocity too; their result is not selected)
+      const float rvx = vbx - avx, rvy = vby - avy;
+      const float vn = pbDot(rvx, rvy, nx, ny);
+      const float tvx = rvx - vn * nx, tvy = rvy - vn * ny;
+      const float ks = -P.spring * (reach - dist);
+      float cx = ks * nx;
+      float cy = ks * ny;
+      cx += P.damping * rvx;
+      cy += P.damping * rvy;
+      cx += P.shear * tvx;
+      cy += P.shear * tvy;
+      pushRep(contact && live, pbDot(cx, cy, cx, cy));
+      tx = contact ? cx : tx;
+      ty = contact ? cy : ty;
+    }
   }
   PbPairXY r;
   r.tx = tx;
