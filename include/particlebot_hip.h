@@ -288,8 +288,11 @@ int pbClockSampleBegin(pbClockSample **out, double seconds);
 int pbClockSampleEnd(pbClockSample *sample, double *mhz, double *seconds_sampled);
 
 /* On-device check that the fast exact forms equal the compiler's IEEE sqrtf and division: every
- * float in the sqrt domain, and div_samples sampled (numerator, numerator, denominator) triples
- * inside the division domain.  Reports how many values were checked and how many differed. */
+ * float in the sqrt domain (pbSqrtFast, and the root of the one-transcendental pair geometry
+ * pbDistUnitFast), and div_samples sampled (numerator, numerator, denominator) triples inside the
+ * division domain (pbDiv2Fast; pbDistUnitFast's unit vector on sampled (d2, dx, dy)).  Reports how many
+ * values were checked and how many differed.  (tools/rsq_form_test.hip is the exhaustive check of
+ * pbDistUnitFast's quotients: all 2^47 mantissa pairs.) */
 int pbSelfTest(unsigned long long div_samples, unsigned long long *sqrt_checked,
                unsigned long long *sqrt_mismatches, unsigned long long *div_checked,
                unsigned long long *div_mismatches);

@@ -70,6 +70,9 @@ constexpr int TILE = PB_TILE;
 #ifndef PB_THROUGHPUT_NB
 #define PB_THROUGHPUT_NB 1
 #endif
+#ifndef PB_PREFETCH_DEPTH
+#define PB_PREFETCH_DEPTH 1  // neighbours in flight ahead of the one being evaluated (throughput sweep)
+#endif
 #ifndef PB_REP_CAP
 #define PB_REP_CAP 8  // pending contact magnitudes per lane before the wave flushes (PbRepList)
 #endif
@@ -416,6 +419,29 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
       vA = vat(loA);
       bounds(si + 2 * stride, loB, hiB);   // bounds of the one after
       if (lo < end) {
+#if PB_PREFETCH_DEPTH == 2
+        // look-ahead of TWO neighbours (three register sets rotating through a loop unrolled by three)
+        OffT off = lo, hoff = lo >> 1;
+        const OffT endm16 = end - 16u, endm32 = end > 32u ? end - 32u : 0u, endm48 = end > 48u ? end - 48u : 0u;
+        float4 q1 = atI(off, 16);
+        float2 v1 = vatI(hoff, 8);
+        for (;;) {
+          const float4 q2 = atI(off, 32);
+          const float2 v2 = vatI(hoff, 16);
+          one(q0, v0, off != selfOff);
+          if (off >= endm16) break;
+          q0 = atI(off, 48);
+          v0 = vatI(hoff, 24);
+          one(q1, v1, off != selfOff - 16u);
+          if (off >= endm32) break;
+          q1 = atI(off, 64);
+          v1 = vatI(hoff, 32);
+          one(q2, v2, off != selfOff - 32u);
+          if (off >= endm48) break;
+          off += 48u;
+          hoff += 24u;
+        }
+#else
         // two neighbours per turn of the loop: `off` is the even one's byte offset, hoff = off / 2 the
         // offset of its velocity
         OffT off = lo, hoff = lo >> 1;
@@ -432,6 +458,7 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
           one(q1, v1, off != selfOff16);
           if (off >= end) break;
         }
+#endif
       }
     }
     if (!ASUM) rep.flush(F.fr);
@@ -1309,6 +1336,13 @@ __global__ __launch_bounds__(256) void k_selftest_sqrt(unsigned long long *__res
     const float x = __uint_as_float(bits);
     seen++;
     if (__float_as_uint(pbSqrtFast(x)) != __float_as_uint(sqrtf(x))) bad++;
+    // the one-transcendental pair geometry: its root for the same x (0 or >= 2^-96)
+    // (finite x: the force kernel never sees an infinite d2 -- positions are clamped to the walls)
+    if (bits != 0x7F800000u) {
+      float dist, nx, ny;
+      pbDistUnitFast(0.0f, 0.0f, x, dist, nx, ny);
+      if (__float_as_uint(dist) != __float_as_uint(sqrtf(x))) bad++;
+    }
   }
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
   if (seen) atomicAdd(checked, (unsigned long long)seen);
@@ -1352,6 +1386,36 @@ __global__ __launch_bounds__(256) void k_selftest_div(unsigned long long samples
     seen += 2;
     if (__float_as_uint(qa) != __float_as_uint(a / d)) bad++;
     if (__float_as_uint(qb) != __float_as_uint(b / d)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+  if (seen) atomicAdd(checked, seen);
+}
+
+// sampled pair geometry: d2 in [2^-88, 2^28] (what the force kernel can see), two coordinate differences no
+// larger than the distance (either sign, or exactly +0): pbDistUnitFast against sqrtf and IEEE division.
+// (The exhaustive version -- every mantissa pair, 2^47 divisions -- is tools/rsq_form_test.hip.)
+__global__ __launch_bounds__(256) void k_selftest_geom(unsigned long long samplesPerThread,
+                                                       unsigned long long *__restrict__ mismatches,
+                                                       unsigned long long *__restrict__ checked) {
+  const uint64_t tid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  unsigned long long bad = 0, seen = 0;
+  for (unsigned long long k = 0; k < samplesPerThread; k++) {
+    const uint64_t h1 = pbMix64(tid * samplesPerThread + k + 0x5151ull), h2 = pbMix64(h1 ^ 0x9E3779B97F4A7C15ull);
+    const uint32_t ed = 127u - 88u + (uint32_t)(h2 % 117u);
+    const float d2 = __uint_as_float(((uint32_t)h1 & 0x007FFFFFu) | (ed << 23));
+    const float ref = sqrtf(d2);
+    const uint32_t eref = (__float_as_uint(ref) >> 23) & 255u;
+    float a = __uint_as_float(((uint32_t)(h1 >> 32) & 0x807FFFFFu) | ((eref - (uint32_t)((h2 >> 8) % 45u)) << 23));
+    float b = __uint_as_float(((uint32_t)(h2 >> 32) & 0x807FFFFFu) | ((eref - (uint32_t)((h2 >> 16) % 45u)) << 23));
+    if (((h2 >> 24) & 15u) == 0u) a = 0.0f;
+    if (!(fabsf(a) <= ref) || !(fabsf(b) <= ref)) continue;
+    if ((a != 0.0f && fabsf(a) < 0x1p-100f) || fabsf(b) < 0x1p-100f) continue;
+    float dist, nx, ny;
+    pbDistUnitFast(a, b, d2, dist, nx, ny);
+    seen += 2;
+    if (__float_as_uint(dist) != __float_as_uint(ref)) bad++;
+    if (__float_as_uint(nx) != __float_as_uint(a / ref)) bad++;
+    if (__float_as_uint(ny) != __float_as_uint(b / ref)) bad++;
   }
   if (bad) atomicAdd(mismatches, bad);
   if (seen) atomicAdd(checked, seen);
@@ -2235,6 +2299,7 @@ int pbSelfTest(unsigned long long div_samples, unsigned long long *sqrt_checked,
   if (per) {
     hipLaunchKernelGGL(k_selftest_div, dim3(4096), dim3(256), 0, 0, per, 0, d + 3, d + 2);
     hipLaunchKernelGGL(k_selftest_div, dim3(4096), dim3(256), 0, 0, per, 1, d + 3, d + 2);
+    hipLaunchKernelGGL(k_selftest_geom, dim3(4096), dim3(256), 0, 0, per, d + 3, d + 2);
   }
   PB_TRY(hipGetLastError());
   unsigned long long h[4];

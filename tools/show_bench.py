@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Print the figures of a bench.py JSON line that the docs quote.  usage: tools/show_bench.py file.json"""
+import json
+import sys
+
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("value", f"{d['value']:.4g}", d["unit"], "| ms/step", round(d["ms_per_step"], 5), "| n_gpus", d["n_gpus"], "| steps", d["steps"])
+print("config", {k: v for k, v in d["config"].items() if k not in ("workload", "force_sums_note")})
+r = d.get("roofline")
+if r:
+    print("roofline frac", round(r["frac"], 4), "achieved", round(r["achieved"], 1), r["unit"], "avg_launch_us",
+          round(r.get("avg_launch_us", 0), 2), "clock", r.get("shader_clock_mhz"), "traffic", r.get("traffic"))
+    v = r.get("valu")
+    if v:
+        print("valu: per wave", round(v["valu_insts_per_wave"]), "trans", round(v["trans_per_wave"]),
+              "frac datasheet@measured", v.get("frac_datasheet_at_measured_clock"), "frac microbench", v.get("frac_microbenchmark_rate"))
+keep = ("value", "us_per_step", "ms_per_step", "us_per_step_per_1e6_bots", "cores", "sims_per_s", "value_1_thread",
+        "finite_at_end", "bots", "members")
+for k in ("both_sums", "large_arena", "random_blob", "streamlined", "cpu_baseline", "ensemble_leg", "survey_literal_lattice"):
+    x = d.get(k)
+    if x:
+        print(k, {kk: x[kk] for kk in x if kk in keep})
+for k in ("sims_per_s", "members_per_rank", "placement_s"):
+    if k in d:
+        print(k, d[k])
