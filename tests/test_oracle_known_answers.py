@@ -142,3 +142,213 @@ def test_zero_Nx_falls_back_to_the_placement_size(orc):
     s3 = orc.Sim(P3)
     s3.run(30)
     assert not np.array_equal(s.get("rad"), s3.get("rad"))
+
+
+# ---- obstacles, friction, kick (impl.cuh:701-831), shadow + phase (impl.cuh:184-290), constrained
+# ---- contraction (impl.cuh:166-172): one isolated bot, every value worked out here in numpy float32
+
+def collide_one(orc, P, pos, vel, rad, dt=0.01):
+    """orc_collide on ONE bot alone in its cell: (new velocity, absForce_a, absForce_r)."""
+    pos, vel, radv = np.array([pos], f), np.array([vel], f), np.array([rad], f)
+    h, idx = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+    orc.lib().orc_calcHash(C.byref(P), h, idx, pos.reshape(-1), 1)
+    start = np.full(P.numCells, 0xFFFFFFFF, np.uint32)
+    end = np.zeros(P.numCells, np.uint32)
+    start[h[0]], end[h[0]] = 0, 1
+    newVel, fa, fr = np.zeros(2, f), np.zeros(1, f), np.zeros(1, f)
+    orc.lib().orc_collide(C.byref(P), newVel, fa, fr, pos.reshape(-1), vel.reshape(-1), radv, idx, start, end, 1,
+                          float(dt))
+    return newVel, fa[0], fr[0]
+
+
+def length(x, y):
+    return np.sqrt(f(f(x * x) + f(y * y)))
+
+
+def friction_and_kick(P, fx, fy, vx, vy, dt):
+    """impl.cuh:799-825 for an ordinary bot."""
+    fric, grav = f(P.friction), f(P.gravity)
+    if length(vx, vy) < f(0.000001) and length(fx, fy) < f(f(f(2.0) * fric) * grav):
+        fx = fy = f(0)
+    vx, vy = f(vx + f(fx * dt)), f(vy + f(fy * dt))
+    k = f(f(fric * grav) * dt)
+    sp = length(vx, vy)
+    if sp < k:
+        return f(0), f(0)
+    return f(vx - f(k * f(vx / sp))), f(vy - f(k * f(vy / sp)))
+
+
+def test_circle_obstacle_contact(orc):
+    P = orc.default_params(nCells=1, nDead=0, seed=1, n_cir_obstacles=1, x_cir_obs=[1.0], y_cir_obs=[0.5],
+                           r_cir_obs=[0.4])
+    px, py, vx, vy, rad, dt = f(0.62), f(0.3), f(0.2), f(-0.1), f(0.1), f(0.01)
+    newVel, fa, fr = collide_one(orc, P, (px, py), (vx, vy), rad, dt)
+    ox, oy, orad = f(1.0), f(0.5), f(0.4)
+    ex, ey = f(px - ox), f(py - oy)
+    d2 = f(f(ex * ex) + f(ey * ey))
+    reach = f(rad + orad)
+    assert d2 < f(reach * reach)
+    dx, dy = f(f(-px) + ox), f(f(-py) + oy)
+    ln = length(dx, dy)
+    dx, dy = f(dx / ln), f(dy / ln)
+    rvx, rvy = f(-vx), f(-vy)
+    vn = f(f(rvx * dx) + f(rvy * dy))
+    tvx, tvy = f(rvx - f(vn * dx)), f(rvy - f(vn * dy))
+    k = f(f(f(2.0) * f(P.spring)) * f(reach - np.sqrt(d2)))   # powf(dist_2, 0.5f) -> sqrtf
+    tx = f(f(f(f(0) + f(k * f(-dx))) + f(f(P.damping) * rvx)) + f(f(P.shear) * tvx))
+    ty = f(f(f(f(0) + f(k * f(-dy))) + f(f(P.damping) * rvy)) + f(f(P.shear) * tvy))
+    assert fr == length(tx, ty) and fa == 0
+    ev = friction_and_kick(P, f(f(0) + tx), f(f(0) + ty), vx, vy, dt)
+    assert newVel[0] == ev[0] and newVel[1] == ev[1]
+    assert tx < 0 and ty < 0  # pushed away from the obstacle (which sits up and to the right)
+
+
+def test_rectangle_obstacle_face_and_corner(orc):
+    kw = dict(nCells=1, nDead=0, seed=1, nobstacles=1, x1obs=[1.0], x2obs=[1.4], y1obs=[-0.5], y2obs=[0.5])
+    P = orc.default_params(**kw)
+    dt = f(0.01)
+    # left face: x1 - rad < x < x2 - rad with y inside the wall's span: dir (1, 0), overlap x - x1 + rad
+    px, py, vx, vy, rad = f(0.95), f(0.1), f(0.3), f(0.05), f(0.1)
+    newVel, fa, fr = collide_one(orc, P, (px, py), (vx, vy), rad, dt)
+    dx, dy = f(1.0), f(0.0)
+    overlap = f(f(px - f(1.0)) + rad)
+    rvx, rvy = f(-vx), f(-vy)
+    vn = f(f(rvx * dx) + f(rvy * dy))
+    tvx, tvy = f(rvx - f(vn * dx)), f(rvy - f(vn * dy))
+    k = f(f(f(-2.0) * f(P.spring)) * overlap)
+    tx = f(f(f(f(0) + f(k * dx)) + f(f(P.damping) * rvx)) + f(f(P.shear) * tvx))
+    ty = f(f(f(f(0) + f(k * dy)) + f(f(P.damping) * rvy)) + f(f(P.shear) * tvy))
+    assert fr == length(tx, ty) and fa == 0
+    ev = friction_and_kick(P, f(f(0) + tx), f(f(0) + ty), vx, vy, dt)
+    assert newVel[0] == ev[0] and newVel[1] == ev[1] and tx < 0
+    # corner (x1, y2): outside both spans, within one radius of the corner
+    px, py, vx, vy = f(0.95), f(0.56), f(0.0), f(-0.2)
+    newVel, fa, fr = collide_one(orc, P, (px, py), (vx, vy), rad, dt)
+    cx, cy = f(px - f(1.0)), f(py - f(0.5))
+    c2 = f(f(cx * cx) + f(cy * cy))
+    assert c2 < f(rad * rad)
+    ln = length(cx, cy)
+    dx, dy = f(f(-cx) / ln), f(f(-cy) / ln)
+    overlap = f(rad - np.sqrt(c2))
+    rvx, rvy = f(-vx), f(-vy)
+    vn = f(f(rvx * dx) + f(rvy * dy))
+    tvx, tvy = f(rvx - f(vn * dx)), f(rvy - f(vn * dy))
+    k = f(f(f(-2.0) * f(P.spring)) * overlap)
+    tx = f(f(f(f(0) + f(k * dx)) + f(f(P.damping) * rvx)) + f(f(P.shear) * tvx))
+    ty = f(f(f(f(0) + f(k * dy)) + f(f(P.damping) * rvy)) + f(f(P.shear) * tvy))
+    assert fr == length(tx, ty)
+    ev = friction_and_kick(P, f(f(0) + tx), f(f(0) + ty), vx, vy, dt)
+    assert newVel[0] == ev[0] and newVel[1] == ev[1]
+    assert tx < 0 and ty > 0  # away from the corner: left and up
+
+
+def test_friction_hold_and_kinetic_friction(orc):
+    P = orc.default_params(nCells=1, nDead=0, seed=1)
+    dt = f(0.01)
+    # at rest with no force: held (velocity stays exactly zero)
+    newVel, fa, fr = collide_one(orc, P, (0.3, 0.3), (0.0, 0.0), 0.1, dt)
+    assert newVel[0] == 0 and newVel[1] == 0 and fa == 0 and fr == 0
+    # moving freely: kinetic friction takes friction*gravity*dt off the speed, along the motion
+    vx, vy = f(0.3), f(-0.4)
+    newVel, _, _ = collide_one(orc, P, (0.3, 0.3), (vx, vy), 0.1, dt)
+    ev = friction_and_kick(P, f(0), f(0), vx, vy, dt)
+    assert newVel[0] == ev[0] and newVel[1] == ev[1]
+    k = f(f(f(P.friction) * f(P.gravity)) * dt)
+    assert abs(float(length(newVel[0], newVel[1])) - (0.5 - float(k))) < 1e-6
+    # slower than one friction decrement: stops dead
+    newVel, _, _ = collide_one(orc, P, (0.3, 0.3), (f(0.5) * k, f(0.0)), 0.1, dt)
+    assert newVel[0] == 0 and newVel[1] == 0
+
+
+def test_update_phase_and_shadow_modes(orc):
+    # the light at (-5, 0); bot 0 in plain view, bot 1 behind a circular obstacle, bot 2 behind a wall
+    base = dict(nCells=3, nDead=0, seed=1, light_x=-5.0, light_y=0.0, n_cir_obstacles=1, x_cir_obs=[-2.0],
+                y_cir_obs=[1.0], r_cir_obs=[0.3], nobstacles=1, x1obs=[-2.0], x2obs=[-1.8], y1obs=[-1.5], y2obs=[-0.5])
+    pos = np.array([[1.0, 0.0], [1.0, 2.0], [1.0, -2.0]], f)
+    spacing, min_d = f(0.155), f(5.9)
+    lx, ly = f(-5.0), f(0.0)
+    want_visible = []
+    for p in pos:
+        d = length(f(p[0] - lx), f(p[1] - ly))
+        want_visible.append(f(f(f(min_d - d) / spacing) * f(2.0)))          # rise_period 2.0
+    for mode in (0, 1, 2):
+        P = orc.default_params(light_shadow=mode, **base)
+        phase = np.full(3, 123.0, f)
+        orc.lib().orc_updatePhase(C.byref(P), pos.reshape(-1).copy(), phase, float(spacing), 0.0, float(min_d), 3)
+        assert phase[0] == want_visible[0]
+        if mode == 0:
+            assert phase[1] == want_visible[1] and phase[2] == want_visible[2]
+        elif mode == 1:
+            shadow = f(f(-(P.Nx - 1)) * f(2.0))                              # -(Nx-1)*rise_period
+            assert phase[1] == shadow and phase[2] == shadow
+        else:
+            assert phase[1] == f(9999999999.0) and phase[2] == f(9999999999.0)
+    # geometry check of the scenario itself (double precision): the sight lines really are blocked
+    for p, (c, r) in ((pos[1], ((-2.0, 1.0), 0.3)),):
+        a, d = np.array([-5.0, 0.0]), np.array(p, float) - np.array([-5.0, 0.0])
+        t = np.dot(np.array(c) - a, d) / np.dot(d, d)
+        assert 0 < t < 1 and np.linalg.norm(a + t * d - np.array(c)) < r
+    t = (-2.0 + 5.0) / (1.0 + 5.0)   # the ray to bot 2 crosses x = -2 at y = -2 t
+    assert -1.5 < -2.0 * t < -0.5
+
+
+def test_constrained_contraction_branch(orc):
+    """impl.cuh:166-172: with constrained_contraction the radius may only shrink as fast as the attraction
+    load allows, and never faster than max_radius * dt (not binding here: the target is 0.001 below the radius)."""
+    P = orc.default_params(nCells=3, nDead=0, seed=1, constrained_contraction=1, constraint_contraction=10.0)
+    n, dt = 3, f(0.01)
+    rad0 = np.full(n, 0.0985, f)
+    absA = np.array([0.0, 0.05, 50.0], f)       # no load, light load, heavy load
+    absR = np.zeros(n, f)
+    rad = rad0.copy()
+    # time1 = 3.0: contraction phase, target = max + (min-max)/rise * (time1 - rise)
+    orc.lib().orc_updateRad_light_wave(C.byref(P), absA, absR, rad, np.zeros(n, f), 3.0, float(dt),
+                                       np.zeros(n, np.int32), n)
+    target = f(f(0.1175) + f(f(f(f(0.0775) - f(0.1175)) / f(2.0)) * f(f(3.0) - f(2.0))))
+    dr1 = f(target - f(0.0985))
+    assert dr1 < 0
+    cc = f(10.0)
+    for i in range(n):
+        dr = f(0)
+        load = f(absA[i] * f(0.0985))
+        if f(f(-cc) * dr1) > load:
+            dr = f(f(f(cc * dr1) + load) / cc)
+        dr = max(dr, f(f(-f(0.1175)) * dt))
+        want = f(f(0.0985) + dr)
+        want = min(max(want, f(0.0775)), f(0.1175))
+        assert rad[i] == want, (i, rad[i], want)
+    assert rad[0] < rad[1] < rad[2] == rad0[2]   # the heavier the attraction load, the less it shrinks
+
+
+def test_dump_csv_bytes(orc, tmp_path):
+    """dumpParticlebot (particlebot.cpp:303-367): header at time 0 ("Seed, %u", the column names with the
+    reference's comma/space pattern), then per row "%f," time, positions "%f, %f,", velocities, radii,
+    centroid and distance "%f, %f, %f," -- expected text assembled here from those format strings."""
+    n = 3
+    P = orc.default_params(nCells=n, nDead=0, seed=4242, phase_std=0.0, max_time=1e9, light_x=-2.0, light_y=1.5)
+    s = orc.Sim(P, reset=True)
+    pos = np.array([[0.25, -0.5], [1.0, 2.0], [-3.125, 0.0625]], f)
+    vel = np.array([[0.0, 0.001], [-0.25, 0.5], [0.0, 0.0]], f)
+    rad = np.array([0.0775, 0.1, 0.1175], f)
+    s.set("pos", pos), s.set("vel", vel), s.set("rad", rad)
+    path = tmp_path / "dump.csv"
+    assert s.dump(str(path), dump_interval=60.0, testing=1, mode="w")
+    cx = f(f(f(f(0) + pos[0, 0]) + pos[1, 0]) + pos[2, 0]) / f(3)
+    cy = f(f(f(f(0) + pos[0, 1]) + pos[1, 1]) + pos[2, 1]) / f(3)
+    dx, dy = f(cx - f(-2.0)), f(cy - f(1.5))
+    dist = f(np.sqrt(np.float64(f(f(dx * dx) + f(dy * dy)))))   # powf(powf(.,2)+powf(.,2), 0.5)
+    want = "Seed, 4242\nTime,"
+    want += "".join(f"Particlebot_{i}_xpos, Particlebot_{i}_ypos," for i in range(n))
+    want += "".join(f"Particlebot_{i}_xvel, Particlebot_{i}_yvel," for i in range(n))
+    want += "".join(f"Particlebot_{i}_rad," for i in range(n))
+    want += "Centroid X, Centroid Y, Distance\n"
+    want += "%f," % 0.0
+    want += "".join("%f, %f," % (float(p[0]), float(p[1])) for p in pos)
+    want += "".join("%f, %f," % (float(v[0]), float(v[1])) for v in vel)
+    want += "".join("%f," % float(r) for r in rad)
+    want += "%f, %f, %f,\n" % (float(cx), float(cy), float(dist))
+    assert path.read_text() == want
+    # a dump call away from a multiple of dump_interval writes nothing (particlebot.cpp:309-310)
+    s.run(2)
+    assert not s.dump(str(path), dump_interval=60.0, testing=1, mode="a")
+    assert path.read_text() == want
