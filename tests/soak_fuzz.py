@@ -62,6 +62,8 @@ def one(pb, orc, trial, seed0):
         gsim.set_resident(2)
     elif form.startswith("variant"):
         gsim.set_force_variant(int(form[-1]))
+    if rng.random() < 0.3:     # both magnitude sums kept although nothing may read absForce_a
+        gsim.set_force_sums(1)
     si = float(rng.choice([0.23, 1.7, 180.0]))
     step = 0
     marks = sorted({1, int(rng.integers(2, 40)), int(rng.integers(290, 420)), int(rng.integers(600, 1300))})

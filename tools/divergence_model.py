@@ -8,7 +8,8 @@ oracle state of the bench workload (CPU only) and counts wave iterations under
       iteration only when every lane is parked or done with the segment
 
 priced with the instruction counts of the shipped kernel (common part A, far tail, contact tail).
-    python tools/divergence_model.py [side] [steps]
+    python tools/divergence_model.py [side] [steps]            bench lattice of side x side bots
+    python tools/divergence_model.py blob [bots] [steps]        random blob (the reference's placement rule)
 """
 import sys
 import numpy as np
@@ -17,23 +18,32 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 import bench
 from oracle import orclib
 
-side = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-n = side * side
-P = orclib.default_params(nCells=n, nDead=0, seed=1, phase_std=0.0, max_time=1e9, light_x=-230.0, light_y=0.0,
-                          grid=2048, arena_half=240.0)
+blob = len(sys.argv) > 1 and sys.argv[1] == "blob"
 orclib.lib().orc_set_num_threads(orclib.usable_cpus())
-sim = orclib.Sim(P, reset=True, hex=True)
-pos0 = bench.square_lattice(n, bench.LATTICE_PITCH)
-sim.set("pos", pos0)
+if blob:
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+    P = orclib.default_params(nCells=n, nDead=0, seed=7, phase_std=0.6, max_time=1e9, light_x=-40.0, light_y=0.0)
+    sim = orclib.Sim(P, reset=True)
+    pos0 = sim.get("pos").copy()
+    ORIGIN, G = 64.0, 512
+else:
+    side = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    n = side * side
+    P = orclib.default_params(nCells=n, nDead=0, seed=1, phase_std=0.0, max_time=1e9, light_x=-230.0, light_y=0.0,
+                              grid=2048, arena_half=240.0)
+    sim = orclib.Sim(P, reset=True, hex=True)
+    pos0 = bench.square_lattice(n, bench.LATTICE_PITCH)
+    sim.set("pos", pos0)
+    ORIGIN, G = 240.0, 2048
 sim.run(steps)
 pos, rad = sim.get("pos").astype(np.float64), sim.get("rad").astype(np.float64)
 
 cell = float(np.float32(0.1175) * np.float32(2))
-G = 2048
 def cells(p):
-    return (np.floor((p[:, 0] + 240.0) / cell).astype(np.int64) & (G - 1),
-            np.floor((p[:, 1] + 240.0) / cell).astype(np.int64) & (G - 1))
+    return (np.floor((p[:, 0] + ORIGIN) / cell).astype(np.int64) & (G - 1),
+            np.floor((p[:, 1] + ORIGIN) / cell).astype(np.int64) & (G - 1))
 gx0, gy0 = cells(pos0.astype(np.float64))       # the stale sort of step 0
 order = np.argsort(gy0 * G + gx0, kind="stable")
 spos, srad = pos[order], rad[order]
