@@ -241,7 +241,7 @@ int pbSimSetForceSums(pbSim *sim, int mode);
 /* Lanes per bot in the per-step force kernel: 1 = throughput form (one bot per lane); 2, 4, 8, 16 =
  * that many adjacent lanes share a bot's neighbour list and add the terms in list order (batches
  * too small to fill the chip: the serial neighbour loop is the limit); 0 = automatic (default:
- * 16 up to 8192 bots in the batch, 8 up to 49152, 4 up to 131072, else 1).  Results do not depend
+ * 16 up to 8192 bots in the batch, 8 up to 40960, 4 up to 131072, else 1).  Results do not depend
  * on it. */
 int pbSimSetLanesPerBot(pbSim *sim, int lanes);
 /* Resident form for simulations of at most 1024 bots: one workgroup per simulation keeps the state

@@ -1543,14 +1543,15 @@ PbForcePlan forcePlan(const pbSim *S) {
   p.kind = S->variant == 0 ? 0 : (S->variant == 1 || !S->fastOk) ? 1 : 2;
   // A per-step launch of a small or medium batch is bound by one wave's serial neighbour loop, not
   // by VALU throughput, so bots get L = 8 or 4 lanes each while the chip has lanes to spare
-  // (measured on MI355X, one simulation on the bench lattice, us/step for L = 1/2/4/8:
-  //  3x10^4 bots 25/18/13/12, 6x10^4 28/21/18.5/20, 10^5 32/26/25.7/29, 2x10^5 35/40/42/49;
-  //  L = 8 vs 16: 300 bots 6.4/5.7, 4000 bots 7.0/6.0, 10^4 bots 7.8/8.0).
+  // (measured on MI355X, one simulation on the bench lattice, us/step for L = 1/2/4/8/16, dead-sum forms,
+  //  profiles/r2_lanes_sweep.txt: 300 bots 21.2/13.0/8.8/6.6/5.7, 8192 bots 25.6/14.4/9.5/7.1/6.6,
+  //  12000 bots 22.4/14.4/9.5/7.6/7.7, 3x10^4 22.1/14.6/10.6/10.5/12.8, 49152 22.1/16.4/13.1/14.0/17.6,
+  //  10^5 28.3/21.7/21.5/23.7/30.6, 131072 27.9/24.6/25.0/28.1/37.2, 2x10^5 27.2/31.1/33.4/39.2/53.6).
   // Only the branch-free kernels have the multi-lane forms.
   if (p.kind != 0) {
     const int want = S->lanesPerBot;
     if (want == 16 || (want == 0 && S->total <= 8192u)) p.form = 16;
-    else if (want == 8 || (want == 0 && S->total <= 49152u)) p.form = 8;
+    else if (want == 8 || (want == 0 && S->total <= 40960u)) p.form = 8;
     else if (want == 4 || (want == 0 && S->total <= 131072u)) p.form = 4;
     else if (want == 2) p.form = 2;
     // the dead-sum forms exist for the branch-free kernels
@@ -1620,17 +1621,21 @@ bool residentWanted(const pbSim *S) {
   if (S->resident == 1 || S->variant == 0 || S->resortEveryStep || residentLanes(S->n) == 0) return false;
   if (S->lanesPerBot != 0 && S->resident != 2) return false;  // an explicit per-step form was asked for
   if (S->resident == 2) return true;
-  // automatic: cost model fitted to MI355X measurements (microseconds per timestep of the whole
-  // batch).  One CU per simulation costs ~3.5 + 0.031 n however many
-  // simulations there are (up to one per CU); a per-step launch costs a ~5.5 us dependent-latency
-  // floor plus a term in the TOTAL number of bots.  So the resident form wins for ensembles of
-  // many small simulations, and loses for a lone simulation that per-step launches spread over
-  // many CUs (at ~100 bots the two are equal).
+  // automatic: cost model fitted to MI355X measurements (microseconds per timestep of the whole batch,
+  // dead-sum forms: profiles/r2_resident_sweep.txt, tools/resident_sweep.py).  One CU
+  // per simulation costs the same however many simulations there are (up to one per CU): 5.3 us at 100
+  // bots, 8.5 at 201, 11.2 at 300, 15.8 at 500, 25.3 at 1000 (the slope changes with the lanes per bot the
+  // simulation's size allows); a per-step launch costs a ~5.5 us dependent-latency floor plus a term in
+  // the TOTAL number of bots that depends on its lanes-per-bot form.  So the resident form wins for
+  // ensembles of many small simulations, and loses for a lone simulation that per-step launches spread
+  // over many CUs (at ~100 bots the two are equal).
   const double n = S->n, total = S->total;
-  const double residentUs =
-      ((S->nsims >= 64u ? 4.0 : 3.0) + 0.031 * n) * (S->nsims > 256u ? S->nsims / 256.0 : 1.0);
-  const double perStepUs = total <= 49152.0 ? 5.3 + total / 5500.0
-                           : total <= 131072.0 ? 9.0 + total / 6000.0 : 17.0 + total / 10300.0;
+  const double oneCu = n <= 128.0 ? 2.6 + 0.027 * n : n <= 256.0 ? 3.0 + 0.0275 * n
+                       : n <= 512.0 ? 4.3 + 0.023 * n : 4.8 + 0.0205 * n;
+  const double residentUs = oneCu * (S->nsims > 256u ? S->nsims / 256.0 : 1.0);
+  const double perStepUs = total <= 8192.0 ? 5.4 + total / 6000.0
+                           : total <= 40960.0 ? 5.6 + total / 7000.0
+                           : total <= 131072.0 ? 6.0 + total / 7800.0 : 18.0 + total / 19000.0;
   return residentUs < perStepUs;
 }
 
