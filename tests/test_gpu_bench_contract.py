@@ -41,6 +41,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     s = d["streamlined"]
     assert s["finite_at_end"] and s["value"] > d["value"] and s["parity"]["window_steps"] == 10
+    # the headline runs the engine's default for the reference's default parameters (constrained_contraction 0:
+    # absForce_a has no reader and is not computed); the same workload with both sums kept is reported beside it
+    assert d["config"]["attraction_sums"] == 0 and d["config"]["dead_sum_form"] == 1
+    b = d["both_sums"]
+    assert b["attraction_sums"] == 1 and b["dead_sum_form"] == 0 and 0 < b["value"] < d["value"] * 1.05
 
 
 def _bench(*args):
