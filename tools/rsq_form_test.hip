@@ -89,6 +89,26 @@ __global__ __launch_bounds__(256) void k_div(unsigned d0, unsigned long long *cn
   if (bad1 && chunk == 0) printf("  d2 = %a (dist %a): r1 %a shipped r %a second-order r %a\n", d2, dist, r1, rc, r2);
 }
 
+// Would pbDiv2Fast survive WITHOUT the Newton step on v_rcp_f32's result (2 instructions per pair less)?
+// every denominator mantissa d in [1, 2) x every numerator mantissa a in [1, 2): 2^46 divisions.
+__global__ __launch_bounds__(256) void k_div_raw(unsigned d0, unsigned long long *cnt) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  const unsigned di = d0 + (t >> 3), chunk = t & 7u;
+  const float d = __uint_as_float(0x3F800000u + di);
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float r1 = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+  unsigned badRaw = 0, badNewton = 0;
+  const unsigned a0 = 0x3F800000u + (chunk << 20);
+  for (unsigned i = 0; i < (1u << 20); i++) {
+    const float a = __uint_as_float(a0 + i);
+    const unsigned ref = __float_as_uint(a / d);
+    badRaw += __float_as_uint(quot(a, d, r0)) != ref;
+    badNewton += __float_as_uint(quot(a, d, r1)) != ref;
+  }
+  if (badRaw) atomicAdd(cnt + 0, (unsigned long long)badRaw);
+  if (badNewton) atomicAdd(cnt + 1, (unsigned long long)badNewton);
+}
+
 // random exponents: d2 in [2^-88, 2^28], a with |a| <= dist (a coordinate difference), any sign
 DEV uint64_t mix(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -127,6 +147,15 @@ int main(int argc, char **argv) {
   unsigned long long *d, h[5];
   hipMalloc(&d, sizeof h);
   hipMemset(d, 0, sizeof h);
+  if (argc > 2 && argv[2][0] == 'r') {   // `rsq_form_test 64 raw`: the pbDiv2Fast-without-Newton question only
+    const unsigned per = (1u << 23) / 64u;
+    for (unsigned sl = 0; sl < slices && sl < 64u; sl++)
+      hipLaunchKernelGGL(k_div_raw, dim3(per * 8u / 256u), dim3(256), 0, 0, sl * per, d);
+    hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    printf("pbDiv2Fast on all %.3g (denominator, numerator) mantissa pairs: mismatches against IEEE division with the raw "
+           "v_rcp_f32 result %llu, with the Newton step (what ships) %llu\n", (double)slices * per * 8388608.0, h[0], h[1]);
+    return 0;
+  }
   hipLaunchKernelGGL(k_sqrt, dim3(1u << 20), dim3(256), 0, 0, d);
   hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
   printf("part 1: %llu floats (0 and [2^-96, FLT_MAX)): sqrt from rsq + 2 Newton steps differs from sqrtf in %llu, "
