@@ -17,7 +17,13 @@ def main():
     ap.add_argument("--sizes", default="300,1000,4000,8192,12000,20000,30000,49152,60000,80000,100000,131072,"
                                        "150000,200000,300000")
     ap.add_argument("--forms", default="1,2,4,8,16")
+    ap.add_argument("--libdir", default=None, help="load the libraries from this directory (experimental builds)")
     args = ap.parse_args()
+    if args.libdir:
+        from particlerobotsimulations_amd import _capi
+        _capi.LIB_DIR = os.path.abspath(args.libdir)
+        _capi.HIP_SO = os.path.join(_capi.LIB_DIR, "libparticlebot_hip.so")
+        _capi.HOST_SO = os.path.join(_capi.LIB_DIR, "libparticlebot_host.so")
     import particlerobotsimulations_amd as pb
     pb.legacy.cudaInit(0, None)
     forms = [int(x) for x in args.forms.split(",")]
