@@ -256,15 +256,36 @@ void Particlebot::_finalize() {
 // ---- stepping ---------------------------------------------------------------------------------
 
 void Particlebot::drawDeadBots() {
-  // particlebot.cpp:178-194: nDead distinct bots, rand() % remaining + erase
-  std::vector<int> inds;
-  inds.reserve(params.nCells);
-  for (uint i = 0; i < params.nCells; i++) inds.push_back((int)i);
+  // particlebot.cpp:178-194: nDead distinct bots, `i = rand() % inds.size(); dead[inds[i]] = 1;
+  // inds.erase(inds.begin() + i)` over inds = 0 .. nCells-1.  The list stays in ascending order, so
+  // inds[i] is the i-th bot still alive: the same bots in the same order come out of a Fenwick tree of
+  // alive flags ("position of the (i+1)-th one", O(log N)) without the erase's O(N) shuffle -- 0.1 s per
+  // member at 10^5 bots, times every member of a dead-fraction sweep, all on one host thread.
+  const uint n = params.nCells;
+  uint top = 1;
+  while (top * 2 <= n) top *= 2;
+  std::vector<uint> tree(n + 1, 0u);
+  for (uint i = 1; i <= n; i++) {  // all alive: node i covers i & -i elements
+    tree[i] += 1u;
+    const uint up = i + (i & (0u - i));
+    if (up <= n) tree[up] += tree[i];
+  }
+  uint remaining = n;
   int count = 0;
-  while (count < params.nDead) {
-    const int i = rng.next() % inds.size();
-    hDead[inds[i]] = 1;
-    inds.erase(inds.begin() + i);
+  while (count < params.nDead && remaining > 0) {
+    uint k = (uint)(rng.next() % remaining) + 1u;  // the k-th alive bot, 1-based
+    uint pos = 0;
+    for (uint step = top; step > 0; step >>= 1) {
+      const uint nxt = pos + step;
+      if (nxt <= n && tree[nxt] < k) {
+        pos = nxt;
+        k -= tree[nxt];
+      }
+    }
+    // pos alive bots precede the one we want: it is bot `pos` (0-based)
+    hDead[pos] = 1;
+    for (uint i = pos + 1; i <= n; i += i & (0u - i)) tree[i] -= 1u;
+    remaining--;
     count++;
   }
   if (engineKind == Engine::Fused) {

@@ -54,6 +54,20 @@ def test_dead_draw_matches_oracle(host, orc):
     assert_bit_equal(dead, o.get("dead"), "dead set")
 
 
+@pytest.mark.parametrize("n,nd", [(1000, 400), (4097, 4096), (6000, 1), (5000, 2500)])
+def test_dead_draw_order_statistics_tree_equals_the_erase_loop(host, orc, n, nd):
+    """The product draws the dead bots from a Fenwick tree of alive flags (O(log N) per bot); the oracle
+    keeps the reference's literal `rand() % size` + vector erase (particlebot.cpp:178-194).  Same bots."""
+    path = os.path.join(ROOT, "examples", "example_dead_cells.cfg")
+    h = host.HostSim(path, engine="host", nCells=str(n), nDead=str(nd))   # (both sides place the blob first: same stream position)
+    P = orc.load_cfg(path, nCells=n, nDead=nd)
+    o = orc.Sim(P, reset=True)
+    dead = h.draw_dead()
+    o.update()
+    assert dead.sum() == nd
+    assert_bit_equal(dead, o.get("dead"), f"dead set of {nd} among {n}")
+
+
 def test_large_placement_matches_oracle(host, orc):
     """10^4 bots (BASELINE config 2b's scale): the accept/reject loop stays in lock-step."""
     path = os.path.join(ROOT, "examples", "example_dead_cells.cfg")
