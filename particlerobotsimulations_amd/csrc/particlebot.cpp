@@ -79,6 +79,52 @@ struct PlacementGrid {
       }
     return false;
   }
+  // Is EVERY point of the circle of radius `ring` around (ax, ay) crowded (closer than `limit` to a listed
+  // disc other than the centre's own)?  A sufficient test with a safety margin far above float rounding:
+  // a disc at distance D blocks the arc |angle - phi| < acos((ring^2 + D^2 - (limit - margin)^2) / (2 ring D));
+  // the circle is covered when the arcs' union is.  Discs only ever get added, so "covered" stays true.
+  // Used by placeRandom to skip the trigonometry and the 9-cell scan for anchors buried in the blob
+  // (nearly all of them: only ~sqrt(i) of i placed discs have room) without changing a single decision.
+  bool ringCovered(float ax, float ay, double ring, double limit) const {
+    const double margin = 1e-3 * limit, lim = limit - margin, reach = ring + lim;
+    const int xc = col(ax), yc = row(ay);
+    const int span = (int)ceil(reach / (cx < cy ? cx : cy));
+    constexpr int kArcs = 128;  // (more discs than that in reach: the extra arcs are ignored -- conservative)
+    double lo[kArcs], hi[kArcs];
+    int m = 0;
+    for (int xg = xc - span; xg <= xc + span; xg++)
+      for (int yg = yc - span; yg <= yc + span; yg++) {
+        if (xg < 0 || yg < 0 || xg >= (int)gx || yg >= (int)gy) continue;
+        for (int b = head[(size_t)xg * gy + yg]; b >= 0; b = node[b].next) {
+          const double dx = (double)node[b].x - ax, dy = (double)node[b].y - ay;
+          const double D = sqrt(dx * dx + dy * dy);
+          if (D < 1e-9 || D >= reach) continue;  // the centre itself / too far to reach the ring
+          const double c = (ring * ring + D * D - lim * lim) / (2.0 * ring * D);
+          if (c >= 1.0) continue;
+          const double w = (c <= -1.0 ? 3.141592653589793 : acos(c)) - 1e-6;
+          if (w <= 0.0 || m == kArcs) continue;
+          const double phi = atan2(dy, dx);
+          lo[m] = phi - w;
+          hi[m] = phi + w;
+          m++;
+        }
+      }
+    if (m == 0) return false;
+    // sort by start (tiny insertion sort), then sweep once around from the first arc
+    for (int i = 1; i < m; i++) {
+      const double l = lo[i], h = hi[i];
+      int j = i - 1;
+      for (; j >= 0 && lo[j] > l; j--) lo[j + 1] = lo[j], hi[j + 1] = hi[j];
+      lo[j + 1] = l, hi[j + 1] = h;
+    }
+    double end = hi[0];
+    const double need = lo[0] + 6.283185307179586 + 1e-9;
+    for (int i = 1; i < m && end < need; i++) {
+      if (lo[i] > end) return false;  // a gap
+      if (hi[i] > end) end = hi[i];
+    }
+    return end >= need;
+  }
 };
 
 }  // namespace
@@ -620,6 +666,11 @@ void Particlebot::placeRandom() {
   hPos[1] = 0.0;
   grid.add(0, 0.0f, 0.0f, hPos[0], hPos[1]);  // sic: the reference bins bot 0 at the origin's cell (:635-637)
   float x = 0, y = 0;
+  // per anchor: bit k-1 = the whole ring of radius 2 k min_radius around it is crowded
+  // (PlacementGrid::ringCovered; the ring widens with the rejection counter), and consecutive crowded draws
+  // (a coverage test costs ~1 us: an anchor on the rim, which fails often without being buried, is re-tested
+  //  after 4, 8, 16, ... crowded draws)
+  std::vector<unsigned char> buried(n, 0), fails(n, 0), retest(n, 4);
   for (uint i = 1; i < n; i++) {
     if (g_verbosePlacement) printf("Placing %d th disc\n", i);
     if (i == 2) {
@@ -638,17 +689,32 @@ void Particlebot::placeRandom() {
       continue;
     }
     float r = params.min_radius;
+    int level = 1;  // r == level * min_radius (as accumulated)
     for (;;) {
       const uint anchor = (uint)rng.next() % i;
       if (rejections == maxRejections) {
         rejections = 0;
         r += params.min_radius;
+        level++;
+      }
+      if (level <= 8 && (buried[anchor] >> (level - 1) & 1)) {
+        // every direction from this anchor is crowded: the draw of the angle is consumed, the outcome known
+        (void)frand(rng);
+        rejections++;
+        continue;
       }
       float theta = 2 * frand(rng) * kPi;
       x = hPos[2 * anchor] + 2 * r * cosf(theta);
       y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
       if (grid.crowded(x, y, touch)) {
         rejections++;
+        if (level <= 8 && ++fails[anchor] >= retest[anchor]) {
+          fails[anchor] = 0;
+          if (grid.ringCovered(hPos[2 * anchor], hPos[2 * anchor + 1], 2.0 * (double)r, touch))
+            buried[anchor] |= (unsigned char)(1u << (level - 1));
+          else if (retest[anchor] < 128)
+            retest[anchor] = (unsigned char)(retest[anchor] * 2);
+        }
         continue;
       }
       const float theta0 = theta;

@@ -68,6 +68,18 @@ def test_dead_draw_order_statistics_tree_equals_the_erase_loop(host, orc, n, nd)
     assert_bit_equal(dead, o.get("dead"), f"dead set of {nd} among {n}")
 
 
+@pytest.mark.parametrize("cfg,n,seed", [("example_dead_cells.cfg", 30000, 31), ("example_object_transport.cfg", 12001, 32)])
+def test_placement_with_buried_anchor_shortcut_matches_oracle(host, orc, cfg, n, seed):
+    """placeRandom skips the trigonometry and the neighbourhood scan for anchors whose whole ring is provably
+    crowded (PlacementGrid::ringCovered, one flag per ring radius) -- 80 % of the draws at 10^5 bots -- while
+    consuming the same rand() draws; the oracle runs the reference's literal loop.  Same blob, bit for bit,
+    at sizes where the ring has widened many times (the rejection counter passes 200 every few bots)."""
+    path = os.path.join(ROOT, "examples", cfg)
+    h = host.HostSim(path, engine="host", nCells=str(n), seed=str(seed))
+    o = orc.Sim(orc.load_cfg(path, nCells=n, seed=seed), reset=True)
+    assert_bit_equal(h.get("pos"), o.get("pos"), f"{cfg} at {n} bots: placement")
+
+
 def test_large_placement_matches_oracle(host, orc):
     """10^4 bots (BASELINE config 2b's scale): the accept/reject loop stays in lock-step."""
     path = os.path.join(ROOT, "examples", "example_dead_cells.cfg")
