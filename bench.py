@@ -742,6 +742,8 @@ def main():
             out["survey_literal_lattice"] = survey_literal(pb, n, args.steps, args.warmup)
         if world == 1 and not args.no_both_sums:
             out["both_sums"] = both_sums_leg(pb, n, args.pitch, min(args.steps, 400), max(args.warmup, 100))
+            # top-level, next to `value`: the same workload with the dead Sum|F_attr| computed all the same
+            out["value_with_both_sums"] = out["both_sums"]["value"]
         if world == 1 and not args.no_streamlined:
             out["streamlined"] = streamlined_leg(pb, n, args.pitch, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
