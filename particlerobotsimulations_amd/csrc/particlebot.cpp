@@ -86,7 +86,13 @@ struct PlacementGrid {
   // Used by placeRandom to skip the trigonometry and the 9-cell scan for anchors buried in the blob
   // (nearly all of them: only ~sqrt(i) of i placed discs have room) without changing a single decision.
   bool ringCovered(float ax, float ay, double ring, double limit) const {
-    const double margin = 1e-3 * limit, lim = limit - margin, reach = ring + lim;
+    // (margin: 0.1 % of the limit, and never less than a few float ulps of the coordinates involved -- the
+    //  candidate point is computed in float, x = ax + 2 r cosf(theta) -- so that a generalised arena thousands
+    //  of units wide cannot make "covered" optimistic)
+    const double ulps = 8.0 * 1.1920929e-7 * (fabs((double)ax) + fabs((double)ay) + ring);
+    const double margin = std::max(1e-3 * limit, ulps);
+    if (margin > 0.25 * limit) return false;
+    const double lim = limit - margin, reach = ring + lim;
     const int xc = col(ax), yc = row(ay);
     const int span = (int)ceil(reach / (cx < cy ? cx : cy));
     constexpr int kArcs = 128;  // (more discs than that in reach: the extra arcs are ignored -- conservative)
