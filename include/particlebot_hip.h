@@ -297,6 +297,14 @@ int pbSelfTest(unsigned long long div_samples, unsigned long long *sqrt_checked,
                unsigned long long *sqrt_mismatches, unsigned long long *div_checked,
                unsigned long long *div_mismatches);
 
+/* The EXHAUSTIVE form of the pair-geometry check: pbDistUnitFast (as the kernels call it) for every d2 of
+ * `slices` consecutive slices (of 64) of [1, 4) -- together all 2^24 mantissa x exponent-parity cases --
+ * against every numerator mantissa (2^23): the root against sqrtf and both quotients against IEEE division.
+ * `checked` counts (d2, numerator) pairs (2^41 per slice, ~1.5 s of one MI355X); all 64 slices are the proof
+ * DESIGN.md section 4 quotes (2^47 pairs, 0 mismatches). */
+int pbSelfTestPairGeometry(unsigned first_slice, unsigned slices, unsigned long long *checked,
+                           unsigned long long *mismatches);
+
 #ifdef __cplusplus
 }
 #endif

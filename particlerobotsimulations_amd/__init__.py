@@ -25,6 +25,15 @@ def self_test(div_samples=1 << 32):
     return {k: int(v.value) for k, v in zip(keys, vals)}
 
 
+def self_test_pair_geometry(first_slice=0, slices=64):
+    """pbSelfTestPairGeometry: pbDistUnitFast against sqrtf and IEEE division on EVERY (d2, numerator)
+    mantissa pair of `slices` of the 64 slices of d2 in [1, 4) (all 64: 2^47 pairs, ~90 s of one MI355X)."""
+    checked, bad = C.c_ulonglong(), C.c_ulonglong()
+    _capi.check(_capi.lib().pbSelfTestPairGeometry(int(first_slice), int(slices), C.byref(checked), C.byref(bad)),
+                "pbSelfTestPairGeometry")
+    return {"checked": int(checked.value), "mismatches": int(bad.value)}
+
+
 def library_paths():
     return {"hip": _capi.HIP_SO, "host": _capi.HOST_SO}
 

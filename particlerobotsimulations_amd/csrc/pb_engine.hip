@@ -1421,6 +1421,30 @@ __global__ __launch_bounds__(256) void k_selftest_geom(unsigned long long sample
   if (seen) atomicAdd(checked, seen);
 }
 
+// EXHAUSTIVE pair geometry (pbSelfTestPairGeometry): pbDistUnitFast -- the function the kernels call, rare
+// path included -- for d2 = every float of a slice of [1, 4) (the 2^24 mantissa x exponent-parity cases, 64
+// slices of 2^18) against every numerator mantissa in [1, 2) (2^23): root vs sqrtf, quotient vs IEEE division.
+// 8 threads per d2, 2^20 numerators each, two numerators per call (the x and the y component).
+__global__ __launch_bounds__(256) void k_selftest_geom_exhaustive(uint32_t d0, unsigned long long *__restrict__ mismatches,
+                                                                  unsigned long long *__restrict__ checked) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t di = d0 + (t >> 3), chunk = t & 7u;
+  const float d2 = __uint_as_float(0x3F800000u + di);
+  const float ref = sqrtf(d2);
+  uint32_t bad = 0;
+  const uint32_t a0 = 0x3F800000u + (chunk << 20);
+  for (uint32_t i = 0; i < (1u << 20); i += 2u) {
+    const float a = __uint_as_float(a0 + i), b = __uint_as_float(a0 + i + 1u);
+    float dist, nx, ny;
+    pbDistUnitFast(a, b, d2, dist, nx, ny);
+    bad += __float_as_uint(dist) != __float_as_uint(ref);
+    bad += __float_as_uint(nx) != __float_as_uint(a / ref);
+    bad += __float_as_uint(ny) != __float_as_uint(b / ref);
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+  if (threadIdx.x == 0) atomicAdd(checked, 256ull << 20);
+}
+
 // ---- shader-clock sampler (diagnostic) ---------------------------------------------------------
 // ONE wave that sleeps for `ticks` of the 100 MHz real-time counter and reports how many shader
 // cycles (s_memtime) went by meanwhile: launched on its own stream beside the force kernels it reads
@@ -2314,6 +2338,24 @@ int pbSelfTest(unsigned long long div_samples, unsigned long long *sqrt_checked,
   if (sqrt_mismatches) *sqrt_mismatches = h[1];
   if (div_checked) *div_checked = h[2];
   if (div_mismatches) *div_mismatches = h[3];
+  return PB_OK;
+}
+
+int pbSelfTestPairGeometry(unsigned first_slice, unsigned slices, unsigned long long *checked,
+                           unsigned long long *mismatches) {
+  if (first_slice >= 64u || slices == 0u || first_slice + slices > 64u) return PB_ERR_ARG;
+  unsigned long long *d = nullptr;
+  PB_TRY(hipMalloc((void **)&d, 2 * sizeof(unsigned long long)));
+  PB_TRY(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+  const uint32_t perSlice = (1u << 24) / 64u;  // d2 values per slice
+  for (unsigned sl = first_slice; sl < first_slice + slices; sl++)
+    hipLaunchKernelGGL(k_selftest_geom_exhaustive, dim3(perSlice * 8u / 256u), dim3(256), 0, 0, sl * perSlice, d + 1, d + 0);
+  PB_TRY(hipGetLastError());
+  unsigned long long h[2];
+  PB_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  PB_TRY(hipFree(d));
+  if (checked) *checked = h[0];
+  if (mismatches) *mismatches = h[1];
   return PB_OK;
 }
 

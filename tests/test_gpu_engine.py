@@ -246,6 +246,16 @@ def test_fast_math_self_test(pb):
     assert r["div_mismatches"] == 0, r
 
 
+def test_pair_geometry_exhaustive_slices(pb):
+    """pbDistUnitFast (one v_rsq_f32 for the distance, its reciprocal and the unit vector) on EVERY (d2, numerator)
+    mantissa pair of two of the 64 slices of d2 in [1, 4): the first, and the last -- which holds the two d2 whose
+    root has an all-ones mantissa, where the wave must take the v_rcp_f32 form.  2^42 pairs here; all 64 slices
+    (2^47, `pb.self_test_pair_geometry()`, profiles/r2_rsq_form_exhaustive.txt) are the proof DESIGN.md quotes."""
+    for first in (0, 63):
+        r = pb.self_test_pair_geometry(first, 1)
+        assert r["checked"] == 1 << 41 and r["mismatches"] == 0, (first, r)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_force_kernel_variants_match_oracle(pb, orc, variant):
     """Reference-shaped, branch-free and fast-exact-math force kernels all match the oracle bit for
