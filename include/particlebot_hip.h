@@ -304,6 +304,10 @@ int pbSelfTest(unsigned long long div_samples, unsigned long long *sqrt_checked,
  * DESIGN.md section 4 quotes (2^47 pairs, 0 mismatches). */
 int pbSelfTestPairGeometry(unsigned first_slice, unsigned slices, unsigned long long *checked,
                            unsigned long long *mismatches);
+/* The same for pbDiv2Fast (the division of the attraction term by gap^2): every denominator mantissa of
+ * `slices` of the 64 slices of [1, 2) against every numerator mantissa: 2^40 quotients per slice, 2^46 in all. */
+int pbSelfTestDivision(unsigned first_slice, unsigned slices, unsigned long long *checked,
+                       unsigned long long *mismatches);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,15 @@ def self_test_pair_geometry(first_slice=0, slices=64):
     return {"checked": int(checked.value), "mismatches": int(bad.value)}
 
 
+def self_test_division(first_slice=0, slices=64):
+    """pbSelfTestDivision: pbDiv2Fast against IEEE division on EVERY (denominator, numerator) mantissa pair of
+    `slices` of the 64 slices of the denominator range (all 64: 2^46 quotients)."""
+    checked, bad = C.c_ulonglong(), C.c_ulonglong()
+    _capi.check(_capi.lib().pbSelfTestDivision(int(first_slice), int(slices), C.byref(checked), C.byref(bad)),
+                "pbSelfTestDivision")
+    return {"checked": int(checked.value), "mismatches": int(bad.value)}
+
+
 def library_paths():
     return {"hip": _capi.HIP_SO, "host": _capi.HOST_SO}
 

@@ -147,6 +147,7 @@ SYMBOLS = {
     "pbClockSampleEnd": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pbSelfTest": (_I, [C.c_ulonglong] + [C.POINTER(C.c_ulonglong)] * 4),
     "pbSelfTestPairGeometry": (_I, [_U, _U, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "pbSelfTestDivision": (_I, [_U, _U, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
 }
 
 _lib = None

@@ -1445,6 +1445,26 @@ __global__ __launch_bounds__(256) void k_selftest_geom_exhaustive(uint32_t d0, u
   if (threadIdx.x == 0) atomicAdd(checked, 256ull << 20);
 }
 
+// EXHAUSTIVE division (pbSelfTestDivision): pbDiv2Fast for every denominator mantissa of a slice of [1, 2)
+// (2^23 values, 64 slices of 2^17) against every numerator mantissa in [1, 2): 2^46 divisions in all.
+__global__ __launch_bounds__(256) void k_selftest_div_exhaustive(uint32_t d0, unsigned long long *__restrict__ mismatches,
+                                                                 unsigned long long *__restrict__ checked) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t di = d0 + (t >> 3), chunk = t & 7u;
+  const float d = __uint_as_float(0x3F800000u + di);
+  uint32_t bad = 0;
+  const uint32_t a0 = 0x3F800000u + (chunk << 20);
+  for (uint32_t i = 0; i < (1u << 20); i += 2u) {
+    const float a = __uint_as_float(a0 + i), b = __uint_as_float(a0 + i + 1u);
+    float qa, qb;
+    pbDiv2Fast(a, b, d, qa, qb);
+    bad += __float_as_uint(qa) != __float_as_uint(a / d);
+    bad += __float_as_uint(qb) != __float_as_uint(b / d);
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+  if (threadIdx.x == 0) atomicAdd(checked, 256ull << 20);
+}
+
 // ---- shader-clock sampler (diagnostic) ---------------------------------------------------------
 // ONE wave that sleeps for `ticks` of the 100 MHz real-time counter and reports how many shader
 // cycles (s_memtime) went by meanwhile: launched on its own stream beside the force kernels it reads
@@ -2350,6 +2370,24 @@ int pbSelfTestPairGeometry(unsigned first_slice, unsigned slices, unsigned long 
   const uint32_t perSlice = (1u << 24) / 64u;  // d2 values per slice
   for (unsigned sl = first_slice; sl < first_slice + slices; sl++)
     hipLaunchKernelGGL(k_selftest_geom_exhaustive, dim3(perSlice * 8u / 256u), dim3(256), 0, 0, sl * perSlice, d + 1, d + 0);
+  PB_TRY(hipGetLastError());
+  unsigned long long h[2];
+  PB_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  PB_TRY(hipFree(d));
+  if (checked) *checked = h[0];
+  if (mismatches) *mismatches = h[1];
+  return PB_OK;
+}
+
+int pbSelfTestDivision(unsigned first_slice, unsigned slices, unsigned long long *checked,
+                       unsigned long long *mismatches) {
+  if (first_slice >= 64u || slices == 0u || first_slice + slices > 64u) return PB_ERR_ARG;
+  unsigned long long *d = nullptr;
+  PB_TRY(hipMalloc((void **)&d, 2 * sizeof(unsigned long long)));
+  PB_TRY(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+  const uint32_t perSlice = (1u << 23) / 64u;  // denominators per slice
+  for (unsigned sl = first_slice; sl < first_slice + slices; sl++)
+    hipLaunchKernelGGL(k_selftest_div_exhaustive, dim3(perSlice * 8u / 256u), dim3(256), 0, 0, sl * perSlice, d + 1, d + 0);
   PB_TRY(hipGetLastError());
   unsigned long long h[2];
   PB_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));

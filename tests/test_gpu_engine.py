@@ -254,6 +254,8 @@ def test_pair_geometry_exhaustive_slices(pb):
     for first in (0, 63):
         r = pb.self_test_pair_geometry(first, 1)
         assert r["checked"] == 1 << 41 and r["mismatches"] == 0, (first, r)
+        r = pb.self_test_division(first, 1)   # pbDiv2Fast, general denominator: 2^40 quotients per slice
+        assert r["checked"] == 1 << 40 and r["mismatches"] == 0, (first, r)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2])
