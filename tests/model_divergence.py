@@ -8,8 +8,9 @@ oracle state of the bench workload (CPU only) and counts wave iterations under
       iteration only when every lane is parked or done with the segment
 
 priced with the instruction counts of the shipped kernel (common part A, far tail, contact tail).
-    python tools/divergence_model.py [side] [steps]            bench lattice of side x side bots
-    python tools/divergence_model.py blob [bots] [steps]        random blob (the reference's placement rule)
+Manual analysis script (not collected by pytest); it lives under tests/ because it drives the oracle.
+    python tests/model_divergence.py [side] [steps]            bench lattice of side x side bots
+    python tests/model_divergence.py blob [bots] [steps]        random blob (the reference's placement rule)
 """
 import sys
 import numpy as np
