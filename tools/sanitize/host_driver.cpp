@@ -50,6 +50,20 @@ int main(int argc, char **argv) {
     pbHostReset(h);
     pbHostDestroy(h);
   }
+  // the reference's placement rule at a size where the ring has widened many times (buried-anchor shortcut,
+  // PlacementGrid::ringCovered) and a large dead-bot draw (order-statistics tree)
+  {
+    char path[512];
+    snprintf(path, sizeof path, "%s/examples/example_dead_cells.cfg", root);
+    void *h = pbHostCreate(path, "nCells\n30000\nnDead\n29999", 2);
+    pbHostReset(h);
+    std::vector<int> dead(30000);
+    pbHostDrawDead(h, dead.data());
+    long nd = 0;
+    for (int d : dead) nd += d;
+    if (nd != 29999) { printf("dead draw count %ld\n", nd); return 1; }
+    pbHostDestroy(h);
+  }
   // O(N) blob at a size where the open list churns, payload mode included
   for (const char *cfgname : {"example.cfg", "example_object_transport.cfg"}) {
     char path[512];
