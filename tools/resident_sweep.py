@@ -41,7 +41,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--members", default="1,8,32,64,128,256")
+    ap.add_argument("--libdir", default=None, help="load the libraries from this directory (experimental builds)")
     args = ap.parse_args()
+    if args.libdir:
+        from particlerobotsimulations_amd import _capi
+        _capi.LIB_DIR = os.path.abspath(args.libdir)
+        _capi.HIP_SO = os.path.join(_capi.LIB_DIR, "libparticlebot_hip.so")
+        _capi.HOST_SO = os.path.join(_capi.LIB_DIR, "libparticlebot_host.so")
     import particlerobotsimulations_amd as pb
     from particlerobotsimulations_amd import host
     pb.legacy.cudaInit(0, None)
