@@ -238,11 +238,11 @@ int pbSimSetForceVariant(pbSim *sim, int variant);
  * root per candidate pair less) and pbSimGetState returns NaN for it.  mode 1: always maintained (valid from the next step on).  Positions,
  * velocities, radii, phases and absForce_r do not depend on the mode. */
 int pbSimSetForceSums(pbSim *sim, int mode);
-/* Lanes per bot in the per-step force kernel: 1 = throughput form (one bot per lane); 2, 4, 8, 16 =
- * that many adjacent lanes share a bot's neighbour list and add the terms in list order (batches
+/* Lanes per bot in the per-step force kernel: 1 = throughput form (one bot per lane); 2, 4, 8, 16, 32,
+ * 64 = that many adjacent lanes share a bot's neighbour list and add the terms in list order (batches
  * too small to fill the chip: the serial neighbour loop is the limit); 0 = automatic (default:
- * 16 up to 8192 bots in the batch, 8 up to 40960, 4 up to 131072, else 1).  Results do not depend
- * on it. */
+ * 64 up to 1280 bots in the batch, 32 up to 2560, 16 up to 8192, 8 up to 40960, 4 up to 131072, else 1).
+ * Results do not depend on it. */
 int pbSimSetLanesPerBot(pbSim *sim, int lanes);
 /* Resident form for simulations of at most 1024 bots: one workgroup per simulation keeps the state
  * in registers/LDS and runs every timestep up to the next re-sort, phase update or end of the

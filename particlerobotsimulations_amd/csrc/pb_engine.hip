@@ -128,12 +128,19 @@ __global__ __launch_bounds__(TILE) void k_state(const PbDevParams *__restrict__ 
 // are never used.  A lane without a term (the bot's own slot, the tail of the list) adds +0, which
 // changes nothing (the sums are never -0).  4 quantities x (L adds + 1 broadcast) instructions per
 // trip; the former form (every lane fetching and adding all L terms itself) took ~12 L.
+// value of the lane to the left: inside a 16-lane DPP row for groups of up to 16 lanes (row_shr:1), across the
+// whole wave for groups of 32 or 64 (wave_shr:1, gfx9)
+template <int L>
 __device__ __forceinline__ float pbShr1(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+  if (L <= 16)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
 }
 template <int L>
 __device__ __forceinline__ float pbGroupLast(float v) {
-  // broadcast the value of the group's last lane to its L lanes (bit-mask mode, inside 32-lane halves)
+  // broadcast the value of the group's last lane to its L lanes (L <= 32: ds_swizzle bit-mask mode inside
+  // 32-lane halves; L == 64: the wave's last lane through an SGPR)
+  if (L == 64) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
   constexpr int PAT = ((L - 1) << 5) | (0x1F & ~(L - 1));
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PAT));
 }
@@ -144,10 +151,10 @@ __device__ __forceinline__ void pbGroupSum(bool live, const PbPairTerm &t, PbFor
   float ax = F.fx + tx, ay = F.fy + ty, aa = F.fa + ta, ar = F.fr + tr;
 #pragma unroll
   for (int e = 1; e < L; e++) {
-    ax = pbShr1(ax) + tx;
-    ay = pbShr1(ay) + ty;
-    aa = pbShr1(aa) + ta;
-    ar = pbShr1(ar) + tr;
+    ax = pbShr1<L>(ax) + tx;
+    ay = pbShr1<L>(ay) + ty;
+    aa = pbShr1<L>(aa) + ta;
+    ar = pbShr1<L>(ar) + tr;
   }
   F.fx = pbGroupLast<L>(ax);
   F.fy = pbGroupLast<L>(ay);
@@ -160,7 +167,7 @@ template <int L>
 __device__ __forceinline__ void pbGroupSum1(float t, float &f) {
   float a = f + t;
 #pragma unroll
-  for (int e = 1; e < L; e++) a = pbShr1(a) + t;
+  for (int e = 1; e < L; e++) a = pbShr1<L>(a) + t;
   f = pbGroupLast<L>(a);
 }
 template <int L>
@@ -169,8 +176,8 @@ __device__ __forceinline__ void pbGroupSumXY(bool live, const PbPairXY &t, PbFor
   float ax = F.fx + tx, ay = F.fy + ty;
 #pragma unroll
   for (int e = 1; e < L; e++) {
-    ax = pbShr1(ax) + tx;
-    ay = pbShr1(ay) + ty;
+    ax = pbShr1<L>(ax) + tx;
+    ay = pbShr1<L>(ay) + ty;
   }
   F.fx = pbGroupLast<L>(ax);
   F.fy = pbGroupLast<L>(ay);
@@ -1589,12 +1596,16 @@ PbForcePlan forcePlan(const pbSim *S) {
   // by VALU throughput, so bots get L = 8 or 4 lanes each while the chip has lanes to spare
   // (measured on MI355X, one simulation on the bench lattice, us/step for L = 1/2/4/8/16, dead-sum forms,
   //  profiles/r2_lanes_sweep.txt: 300 bots 21.2/13.0/8.8/6.6/5.7, 8192 bots 25.6/14.4/9.5/7.1/6.6,
+  //  and for L = 16/32/64 on the final build: 100 bots 5.19/4.85/4.78, 1000 bots 5.39/5.06/4.83, 2000 bots
+  //  5.42/5.09/5.20, 4000 bots 5.52/5.71/6.64,
   //  12000 bots 22.4/14.4/9.5/7.6/7.7, 3x10^4 22.1/14.6/10.6/10.5/12.8, 49152 22.1/16.4/13.1/14.0/17.6,
   //  10^5 28.3/21.7/21.5/23.7/30.6, 131072 27.9/24.6/25.0/28.1/37.2, 2x10^5 27.2/31.1/33.4/39.2/53.6).
   // Only the branch-free kernels have the multi-lane forms.
   if (p.kind != 0) {
     const int want = S->lanesPerBot;
-    if (want == 16 || (want == 0 && S->total <= 8192u)) p.form = 16;
+    if (want == 64 || (want == 0 && S->total <= 1280u)) p.form = 64;
+    else if (want == 32 || (want == 0 && S->total <= 2560u)) p.form = 32;
+    else if (want == 16 || (want == 0 && S->total <= 8192u)) p.form = 16;
     else if (want == 8 || (want == 0 && S->total <= 40960u)) p.form = 8;
     else if (want == 4 || (want == 0 && S->total <= 131072u)) p.form = 4;
     else if (want == 2) p.form = 2;
@@ -1628,11 +1639,15 @@ void launchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int d
 #define PB_CASE(F, PL, K, FL, FA)                                                                        \
   if (fuse == F && payload == PL && kind == K) {                                                         \
     if (FL && !plan.asum) {                                                                                        \
+      if (form == 64) return launchForceT<F, PL, FL, FA, (FL ? 64 : 1), 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext); \
+      if (form == 32) return launchForceT<F, PL, FL, FA, (FL ? 32 : 1), 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext); \
       if (form == 16) return launchForceT<F, PL, FL, FA, (FL ? 16 : 1), 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext); \
       if (form == 8) return launchForceT<F, PL, FL, FA, (FL ? 8 : 1), 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext); \
       if (form == 4) return launchForceT<F, PL, FL, FA, (FL ? 4 : 1), 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext); \
       if (form == 2) return launchForceT<F, PL, FL, FA, (FL ? 2 : 1), 1, false, !FL>(S, c, o, dt, tNext, doRadiusNext); \
     }                                                                                                              \
+    if (FL && form == 64) return launchForceT<F, PL, FL, FA, (FL ? 64 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
+    if (FL && form == 32) return launchForceT<F, PL, FL, FA, (FL ? 32 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 16) return launchForceT<F, PL, FL, FA, (FL ? 16 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 8) return launchForceT<F, PL, FL, FA, (FL ? 8 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
     if (FL && form == 4) return launchForceT<F, PL, FL, FA, (FL ? 4 : 1), 1>(S, c, o, dt, tNext, doRadiusNext); \
@@ -1677,7 +1692,8 @@ bool residentWanted(const pbSim *S) {
   const double oneCu = n <= 128.0 ? 2.6 + 0.027 * n : n <= 256.0 ? 3.0 + 0.0275 * n
                        : n <= 512.0 ? 4.3 + 0.023 * n : 4.8 + 0.0205 * n;
   const double residentUs = oneCu * (S->nsims > 256u ? S->nsims / 256.0 : 1.0);
-  const double perStepUs = total <= 8192.0 ? 5.4 + total / 6000.0
+  const double perStepUs = total <= 2560.0 ? 4.75 + total / 10000.0
+                           : total <= 8192.0 ? 5.4 + total / 6000.0
                            : total <= 40960.0 ? 5.6 + total / 7000.0
                            : total <= 131072.0 ? 6.0 + total / 7800.0 : 18.0 + total / 19000.0;
   return residentUs < perStepUs;
@@ -2322,7 +2338,9 @@ int pbSimSetForceSums(pbSim *S, int mode) {
 }
 
 int pbSimSetLanesPerBot(pbSim *S, int lanes) {
-  if (!S || !(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16)) return PB_ERR_ARG;
+  if (!S || !(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16 || lanes == 32 ||
+              lanes == 64))
+    return PB_ERR_ARG;
   S->lanesPerBot = lanes;
   return PB_OK;
 }

@@ -49,7 +49,7 @@ def main():
         dead = (rng.random(n) < rng.uniform(0.05, 0.4)).astype(np.int32)
         osim.set("dead", dead)
     sp, keep = simparams_from_orc(P)
-    form = rng.choice(["auto", "l1", "l1big", "l2", "l4", "l8", "l16", "resident", "variant0", "variant1"])
+    form = rng.choice(["auto", "l1", "l1big", "l2", "l4", "l8", "l16", "l32", "l64", "resident", "variant0", "variant1"])
     si = float(rng.choice([0.23, 1.7, 180.0]))
     print("form", form, "sort_interval", si, "n", n)
     sims = {}

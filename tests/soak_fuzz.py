@@ -45,7 +45,7 @@ def one(pb, orc, trial, seed0):
         dead = (rng.random(n) < rng.uniform(0.05, 0.4)).astype(np.int32)
         osim.set("dead", dead)
     sp, keep = simparams_from_orc(P)
-    form = rng.choice(["auto", "l1", "l1big", "l2", "l4", "l8", "l16", "resident", "variant0", "variant1"])
+    form = rng.choice(["auto", "l1", "l1big", "l2", "l4", "l8", "l16", "l32", "l64", "resident", "variant0", "variant1"])
     os.environ["PB_ALLOW_ENV_OVERRIDES"] = "1"
     os.environ["PB_DEBUG_FORCE_BIG"] = "1" if form == "l1big" else "0"   # the 64-bit-offset sweep on a small batch
     gsim = pb.Sim(sp, keepalive=keep)

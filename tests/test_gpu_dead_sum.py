@@ -184,7 +184,7 @@ def test_switching_modes_in_mid_run(pb, orc):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("form", ["l2", "l4", "l8", "l16", "resident128", "resident256", "resident512", "resident1024"])
+@pytest.mark.parametrize("form", ["l2", "l4", "l8", "l16", "l32", "l64", "resident128", "resident256", "resident512", "resident1024"])
 def test_multi_lane_and_resident_forms(pb, orc, form, mode):
     """Every lanes-per-bot form of the per-step kernel and all four widths of the resident kernel, with and
     without Sum|F_attr|: payload factors, an obstacle, noise, two re-sorts."""

@@ -38,7 +38,8 @@ def compare(osim, gsim, what):
         assert_bit_equal(st[k], osim.get(k), f"{what}: {k}")
 
 
-FORMS = [("auto", None, 0), ("lanes1", 1, 1), ("lanes2", 2, 1), ("lanes4", 4, 1), ("lanes8", 8, 1), ("lanes16", 16, 1), ("resident", None, 2)]
+FORMS = [("auto", None, 0), ("lanes1", 1, 1), ("lanes2", 2, 1), ("lanes4", 4, 1), ("lanes8", 8, 1), ("lanes16", 16, 1), ("lanes32", 32, 1),
+         ("lanes64", 64, 1), ("resident", None, 2)]
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1023, 1024, 1025])
@@ -157,7 +158,7 @@ def test_huge_arena_with_aliased_cells(pb, orc):
     P = orc.default_params(nCells=n, nDead=0, seed=5, phase_std=0.0, max_time=1e9, light_x=0.0, light_y=0.0,
                            arena_half=2000.0, grid=512)
     assert abs(P.cellSizeX - 0.235) < 0.01  # the default grid geometry, only the walls moved
-    for lanes in (1, 8, 16):
+    for lanes in (1, 8, 16, 64):
         osim, gsim = pair_with_state(pb, orc, P, pos, vel, rad, wall_half=2000.0)
         gsim.set_lanes_per_bot(lanes)
         gsim.set_resident(1)

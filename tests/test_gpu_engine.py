@@ -361,11 +361,11 @@ def test_ensemble_rejects_mismatched_members(pb, orc):
         pb.Ensemble([a, b], keepalive=[ka, kb])
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64])
 @pytest.mark.parametrize("case", ["payload_obstacles", "wrap_walls"])
 def test_lanes_per_bot_forms_match_oracle(pb, orc, lanes, case):
     """The throughput form (one bot per lane) and the multi-lane forms of the per-step force kernel
-    (2, 4, 8, 16 lanes per bot, ordered group sum) add the same terms in the same order: all
+    (2 ... 64 lanes per bot, ordered group sum; 32 and 64 chain across DPP rows with wave_shr) add the same terms in the same order: all
     bit-identical to the oracle, also at the grid's x-wrap where a stencil row splits
     into two slot ranges."""
     rng = np.random.default_rng(5)
