@@ -217,6 +217,16 @@ int pbSimGetStats(pbSim *sim, pbSimStats *stats);
  * 1: re-sort every step (never the default: it changes trajectories). */
 int pbSimSetResortEveryStep(pbSim *sim, int on);
 
+/* How the phase update finds the distance from the light to the nearest bot (particlebot.cpp:214-228: a host
+ * loop of powf(powf(dx,2) + powf(dy,2), 0.5f) over every position).  0 (default): the device reduces
+ * min(dx*dx + dy*dy), 4 bytes per simulation come back and the host takes powf(., 0.5f) -- the reference's value
+ * provided the host libm has powf(x,2) == x*x for every float and a non-decreasing powf(., 0.5f), which
+ * pbHostLibmCheck (libparticlebot_host.so; tests/test_libm_pin.py) verifies exhaustively.  1: the reference's own
+ * loop on the host over all positions (8 n bytes per simulation): no assumption.  pbSetMinDistanceMode sets the
+ * default of batches created afterwards (process-wide). */
+int pbSimSetMinDistanceMode(pbSim *sim, int mode);
+int pbSetMinDistanceMode(int mode);
+
 /* Force-kernel variant of a simulation: 0 reference-shaped branches, 1 branch-free, 2 branch-free
  * with the fast exact sqrt/division forms (default; falls back to 1 when the simulation's
  * constants are outside their proven domain).  Variants 0-2 give bit-identical results.
@@ -264,6 +274,25 @@ int pbSimSetRng(pbSim *sim, int kind);
 /* The generator states of one member in ORIGINAL bot order (n x pbRngState); PB_ERR_ARG with the
  * counter generator, which has none. */
 int pbSimGetRngStatesOf(pbSim *sim, unsigned member, pbRngState *states);
+
+/* The FORMS of the exact per-step force kernel (csrc/pb_force.hip): one table shared by the dispatch and by
+ * the parity tests, so that every shape that can run is enumerable.  flat 0 = reference-shaped branches
+ * (force variant 0), 1 = branch-free (variants 1 and 2; whether the fast exact forms are used is decided at
+ * run time per wave); lanes_per_bot as pbSimSetLanesPerBot; attraction_sums 0 = the dead-sum form (no
+ * Sum|F_attr|, pbSimSetForceSums); offsets64 1 = 64-bit byte offsets in the throughput sweep (what batches of
+ * 2^28 bots and more run).  Every row exists for both payload modes.  All rows give bit-identical results.
+ * pbSimSelectForceForm pins a batch to row `index` (and to per-step launches: the resident form is switched
+ * off); -1 returns to the automatic choices.  A dead-sum row is refused (PB_ERR_ARG) for a batch in which a
+ * member reads absForce_a (constrained_contraction). */
+typedef struct pbForceForm {
+  int flat;
+  int lanes_per_bot;
+  int attraction_sums;
+  int offsets64;
+} pbForceForm;
+int pbForceFormCount(void);
+int pbForceFormGet(int index, pbForceForm *form);
+int pbSimSelectForceForm(pbSim *sim, int index);
 
 typedef struct pbSimConfig {
   int force_variant;

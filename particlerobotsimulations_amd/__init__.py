@@ -43,6 +43,18 @@ def self_test_division(first_slice=0, slices=64):
     return {"checked": int(checked.value), "mismatches": int(bad.value)}
 
 
+def force_forms():
+    """The forms table of the exact per-step force kernel (pbForceFormCount / pbForceFormGet): a list of
+    dicts flat / lanes_per_bot / attraction_sums / offsets64, index = row number."""
+    L = _capi.lib()
+    out = []
+    for i in range(L.pbForceFormCount()):
+        f = _capi.pbForceForm()
+        _capi.check(L.pbForceFormGet(i, C.byref(f)), "pbForceFormGet")
+        out.append({k: int(getattr(f, k)) for k, _ in _capi.pbForceForm._fields_})
+    return out
+
+
 def library_paths():
     return {"hip": _capi.HIP_SO, "host": _capi.HOST_SO}
 
@@ -280,6 +292,10 @@ class Sim:
         """0 (default): absForce_a only when a member reads it (constrained_contraction); otherwise it
         is a dead value, not computed, and get_state() returns NaN for it.  1: always maintained."""
         _capi.check(_capi.lib().pbSimSetForceSums(self._h, int(mode)))
+
+    def select_force_form(self, index):
+        """Pin the batch to row `index` of the force-kernel forms table (force_forms()); -1: automatic."""
+        _capi.check(_capi.lib().pbSimSelectForceForm(self._h, int(index)), "pbSimSelectForceForm")
 
     def set_lanes_per_bot(self, lanes):
         _capi.check(_capi.lib().pbSimSetLanesPerBot(self._h, int(lanes)))

@@ -77,6 +77,10 @@ class pbSimConfig(C.Structure):
                 ("attraction_sums", C.c_int), ("dead_sum_form", C.c_int)]
 
 
+class pbForceForm(C.Structure):
+    _fields_ = [("flat", C.c_int), ("lanes_per_bot", C.c_int), ("attraction_sums", C.c_int), ("offsets64", C.c_int)]
+
+
 # every symbol include/particlebot_hip.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 _F = C.c_float
@@ -134,11 +138,16 @@ SYMBOLS = {
     "pbSimCentroid": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pbSimGetStats": (_I, [_VP, C.POINTER(pbSimStats)]),
     "pbSimSetResortEveryStep": (_I, [_VP, _I]),
+    "pbSimSetMinDistanceMode": (_I, [_VP, _I]),
+    "pbSetMinDistanceMode": (_I, [_I]),
     "pbSimSetForceVariant": (_I, [_VP, _I]),
     "pbSimSetLanesPerBot": (_I, [_VP, _I]),
     "pbSimSetResident": (_I, [_VP, _I]),
     "pbSimGetConfig": (_I, [_VP, C.POINTER(pbSimConfig)]),
     "pbSimSetForceSums": (_I, [_VP, _I]),
+    "pbForceFormCount": (_I, []),
+    "pbForceFormGet": (_I, [_I, C.POINTER(pbForceForm)]),
+    "pbSimSelectForceForm": (_I, [_VP, _I]),
     "pbSimSetRng": (_I, [_VP, _I]),
     "pbSimGetRngStatesOf": (_I, [_VP, _U, _VP]),
     "pbSetRngKind": (_I, [_I]),

@@ -102,6 +102,11 @@ struct PlacementGrid {
       for (int yg = yc - span; yg <= yc + span; yg++) {
         if (xg < 0 || yg < 0 || xg >= (int)gx || yg >= (int)gy) continue;
         for (int b = head[(size_t)xg * gy + yg]; b >= 0; b = node[b].next) {
+          // A disc filed under a cell other than its position's (the reference bins bot 0, at (5,0), under the
+          // ORIGIN's cell, :635-637) is only seen by the 3x3 crowded test of candidates near the cell it is filed
+          // under, not near where it is: it must not count as cover here (conservative: the anchor is then
+          // simply tested the slow way)
+          if (col(node[b].x) != xg || row(node[b].y) != yg) continue;
           const double dx = (double)node[b].x - ax, dy = (double)node[b].y - ay;
           const double D = sqrt(dx * dx + dy * dy);
           if (D < 1e-9 || D >= reach) continue;  // the centre itself / too far to reach the ring
@@ -991,6 +996,11 @@ bool Particlebot::saveCheckpoint(FILE *fp) {
   if (pbSimGetState(sim, hPos, hVel, hRad, hphase, hDead, absA.data(), absR.data()) != PB_OK) return false;
   if (pbSimGetLayoutOf(sim, 0, orig.data(), keys.data(), &sorted) != PB_OK) return false;
   if (pbSimGetPhaseDraws(sim, &draws) != PB_OK) return false;
+  // Sum|F_attr| is not maintained when nothing reads it (pbSimSetForceSums): pbSimGetState hands out NaN for
+  // it then.  Store zeros, so that a resumed run that does keep the sums never starts from NaN.
+  pbSimConfig conf;
+  if (pbSimGetConfig(sim, &conf) != PB_OK) return false;
+  if (!conf.attraction_sums) std::fill(absA.begin(), absA.end(), 0.0f);
   int rs[36];
   rng.getState(rs);
   const int kind = rngKindV;
@@ -1020,6 +1030,8 @@ bool Particlebot::loadCheckpoint(FILE *fp) {
         getv(fp, keys.data(), n)))
     return false;
   if (sorted && pbSimSetLayoutOf(sim, 0, orig.data(), keys.data()) != PB_OK) return false;
+  // (checkpoints written before round 3 hold NaN for a Sum|F_attr| that was not maintained)
+  if (std::all_of(absA.begin(), absA.end(), [](float x) { return x != x; })) std::fill(absA.begin(), absA.end(), 0.0f);
   if (pbSimSetState(sim, hPos, hVel, hRad, hphase, hDead) != PB_OK) return false;
   if (pbSimSetForcesOf(sim, 0, absA.data(), absR.data()) != PB_OK) return false;
   // the generator the run was using (its states are a function of seed, bot and draws made)

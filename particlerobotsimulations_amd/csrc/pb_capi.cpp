@@ -1,5 +1,6 @@
 // pb_capi.cpp -- C wrappers around the C++ host side (class Particlebot + .cfg loader) so that
 // scripts and tests can drive it through ctypes.  Exported from libparticlebot_host.so.
+#include <gnu/libc-version.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -500,6 +501,60 @@ int pbEnsembleGetState(void *ev, int member, float *pos, float *vel, float *rad)
 }
 
 unsigned pbEnsembleNumBots(void *ev) { return ((Ensemble *)ev)->bots[0]->getParams().nCells; }
+
+// ---- the libm properties the phase update rests on (pbSimSetMinDistanceMode 0) ---------------------
+// The engine returns min_i (dx*dx + dy*dy) from the device and takes powf(., 0.5f) on the host, where the
+// reference takes min_i powf(powf(dx,2) + powf(dy,2), 0.5f) (particlebot.cpp:215-228).  The two agree for every
+// input iff, on THIS host's libm, powf(x, 2.0f) == x*x bit for bit for every float and powf(., 0.5f) is
+// non-decreasing over the non-negative floats.  Checked exhaustively: every non-negative float (the square also
+// for every 16th negative one; 2^31 values, ~15 s on 8 cores).  stride > 1 samples every stride-th float.
+// Returns 0 when both hold.
+int pbHostLibmCheck(int threads, unsigned stride, unsigned long long *checked, unsigned long long *square_mismatches,
+                    unsigned long long *root_inversions) {
+  if (threads < 1) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) threads = std::min(threads, CPU_COUNT(&set));
+  threads = std::max(1, std::min(threads, 256));
+  if (stride < 1) stride = 1;
+  const uint64_t last = 0x7F800000ull;  // +inf included
+  std::vector<unsigned long long> bad(threads, 0), inv(threads, 0), seen(threads, 0);
+  auto work = [&](int t) {
+    const uint64_t lo = last * (uint64_t)t / (uint64_t)threads, hi = last * (uint64_t)(t + 1) / (uint64_t)threads;
+    // (each chunk starts one float early so that the monotonicity test spans the chunk boundaries)
+    uint32_t b0 = (uint32_t)(lo == 0 ? 0 : lo - 1);
+    float x0;
+    memcpy(&x0, &b0, 4);
+    float prev = powf(x0, 0.5f);
+    const uint64_t end = (t == threads - 1) ? hi + 1 : hi;  // (+inf belongs to the last chunk)
+    for (uint64_t b = lo; b < end; b += stride) {
+      const uint32_t bits = (uint32_t)b;
+      float x;
+      memcpy(&x, &bits, 4);
+      const float sq = powf(x, 2.0f), mul = x * x;
+      if (memcmp(&sq, &mul, 4) != 0) bad[t]++;
+      if ((bits & 15u) == 0u) {  // the negative argument: every 16th float
+        const float sqn = powf(-x, 2.0f);
+        if (memcmp(&sqn, &mul, 4) != 0) bad[t]++;
+      }
+      const float r = powf(x, 0.5f);
+      if (r < prev) inv[t]++;
+      prev = r;
+      seen[t]++;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
+  work(0);
+  for (auto &th : pool) th.join();
+  unsigned long long b = 0, i = 0, n = 0;
+  for (int t = 0; t < threads; t++) b += bad[t], i += inv[t], n += seen[t];
+  if (checked) *checked = n;
+  if (square_mismatches) *square_mismatches = b;
+  if (root_inversions) *root_inversions = i;
+  return (b == 0 && i == 0) ? 0 : 1;
+}
+
+const char *pbHostLibcVersion(void) { return gnu_get_libc_version(); }
 
 // ---- csrc/pb_xorwow.hpp on the host (CPU tests: the same code the kernels run) -------------------
 static const uint32_t *hostJumpTable() {

@@ -32,6 +32,6 @@ static inline int pbKeyBits(uint32_t numKeys) {
   return b < 1 ? 1 : b;
 }
 
-// ---- XORWOW jump table (pb_xorwow.hpp) on the current device: built on the host once per process,
-// uploaded once; returns nullptr and sets *err after a HIP error (pb_legacy.hip)
+// ---- XORWOW jump table (pb_xorwow.hpp) on the CURRENT device: built on the host once per process,
+// uploaded once per device; returns nullptr and sets *err after a HIP error (pb_legacy.hip)
 const uint32_t *pbXorwowDeviceTable(hipError_t *err);

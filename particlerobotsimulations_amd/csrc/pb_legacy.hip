@@ -9,6 +9,7 @@
 #include <map>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "particlebot_hip.h"
 #include "pb_device.hpp"
@@ -16,23 +17,35 @@
 #include "pb_xorwow.hpp"
 
 const uint32_t *pbXorwowDeviceTable(hipError_t *err) {
+  // one copy per DEVICE (a process may drive batches on several GPUs, pbSim::device): keyed by the
+  // calling thread's current device, which every pbSim entry point has set (useDevice)
   static std::mutex mu;
-  static uint32_t *dev = nullptr;
+  static std::map<int, uint32_t *> perDevice;
+  static std::vector<uint32_t> table;  // built once on the host
   std::lock_guard<std::mutex> lock(mu);
   if (err) *err = hipSuccess;
-  if (dev) return dev;
-  std::vector<uint32_t> table(PB_XW_TABLE_WORDS);
-  pbXorwowBuildJumpTable(table.data());
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) {
+    if (err) *err = e;
+    return nullptr;
+  }
+  auto it = perDevice.find(device);
+  if (it != perDevice.end()) return it->second;
+  if (table.empty()) {
+    table.resize(PB_XW_TABLE_WORDS);
+    pbXorwowBuildJumpTable(table.data());
+  }
   uint32_t *d = nullptr;
-  hipError_t e = hipMalloc((void **)&d, sizeof(uint32_t) * PB_XW_TABLE_WORDS);
+  e = hipMalloc((void **)&d, sizeof(uint32_t) * PB_XW_TABLE_WORDS);
   if (e == hipSuccess) e = hipMemcpy(d, table.data(), sizeof(uint32_t) * PB_XW_TABLE_WORDS, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (err) *err = e;
     if (d) (void)hipFree(d);
     return nullptr;
   }
-  dev = d;
-  return dev;
+  perDevice[device] = d;
+  return d;
 }
 
 namespace {

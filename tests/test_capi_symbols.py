@@ -123,3 +123,25 @@ def test_ensemble_header_symbols_are_exported_by_the_host_library():
         arr = (C.c_char_p * 1)(b"seed\n1")
         cfg = os.path.join(ROOT, "examples", "example_dead_cells.cfg").encode()
         assert L.pbEnsembleCreate(cfg, None, arr, 1) is None
+
+
+def test_force_forms_table_is_enumerable_without_a_gpu(capi):
+    """The forms table of the exact force kernel (csrc/pb_force.hip): 17 distinct rows -- the reference-shaped
+    kernel, the throughput form with 32- and 64-bit offsets, 2..64 lanes per bot, each branch-free shape with
+    and without Sum|F_attr| -- and the index checks of its accessors."""
+    import ctypes as C
+    L = capi.lib()
+    n = L.pbForceFormCount()
+    assert n == 17
+    rows = set()
+    for i in range(n):
+        f = capi.pbForceForm()
+        assert L.pbForceFormGet(i, C.byref(f)) == 0
+        rows.add((f.flat, f.lanes_per_bot, f.attraction_sums, f.offsets64))
+        assert f.lanes_per_bot in (1, 2, 4, 8, 16, 32, 64)
+        assert f.flat or (f.lanes_per_bot == 1 and f.attraction_sums == 1 and f.offsets64 == 0)
+        assert not f.offsets64 or f.lanes_per_bot == 1
+    assert len(rows) == n
+    f = capi.pbForceForm()
+    assert L.pbForceFormGet(n, C.byref(f)) == 2 and L.pbForceFormGet(-1, C.byref(f)) == 2
+    assert L.pbSimSelectForceForm(None, 0) == 2

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import assert_bit_equal, jittered_blob, simparams_from_orc
+from particlerobotsimulations_amd import _capi
 
 pytestmark = pytest.mark.gpu
 
@@ -247,12 +248,15 @@ def test_sixty_four_bit_offset_sweep_on_a_small_batch(pb, orc, case, monkeypatch
         compare(osim, gsim, f"64-bit offsets, {case}, step {k}")
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("nan_at", [(0,), (5, 70), (149,), (3, 149)])
-def test_phase_update_follows_the_reference_loop_when_positions_are_nan(pb, orc, nan_at):
+def test_phase_update_follows_the_reference_loop_when_positions_are_nan(pb, orc, nan_at, mode):
     """A blown-up simulation: the reference's min-distance loop `min_d = (min_d < dist ? min_d : dist)`
     (particlebot.cpp:217-227) lets a NaN distance replace the running minimum and the next bot's distance
     replace the NaN, i.e. it returns the minimum over the bots AFTER the last NaN one (NaN if that is the
-    last bot).  The engine's on-device reduction must give the same phases (found by tests/soak_fuzz.py)."""
+    last bot).  The engine's on-device reduction must give the same phases (found by tests/soak_fuzz.py), and so
+    must its host-loop form (pbSimSetMinDistanceMode 1, the fallback for hosts whose libm fails
+    tests/test_libm_pin.py)."""
     n = 150
     P = orc.default_params(nCells=n, nDead=0, seed=21, phase_std=0.0, max_time=1e9, light_x=-3.0, light_y=2.0)
     osim = orc.Sim(P, reset=True)
@@ -265,6 +269,7 @@ def test_phase_update_follows_the_reference_loop_when_positions_are_nan(pb, orc,
     sp, keep = simparams_from_orc(P)
     gsim = pb.Sim(sp, keepalive=keep)
     gsim.set_state(pos=pos, vel=osim.get("vel"), rad=osim.get("rad"), phase=osim.get("phase"), dead=osim.get("dead"))
+    _capi.check(_capi.lib().pbSimSetMinDistanceMode(gsim._h, mode))
     osim.run(1)
     gsim.step(1)
     a, b = gsim.get_state()["phase"], osim.get("phase")

@@ -308,6 +308,16 @@ def test_fast_math_disabled_for_out_of_domain_constants(pb, orc):
 
 @pytest.mark.parametrize("resident", [1, 2])
 def test_ensemble_batch_matches_individual_oracles(pb, orc, resident):
+    _ensemble_batch_vs_oracles(pb, orc, resident, 0)
+
+
+def test_ensemble_batch_with_the_host_loop_minimum_matches_individual_oracles(pb, orc):
+    """pbSimSetMinDistanceMode 1: the phase update's nearest-bot distance from the reference's own host loop over
+    every position (the fallback for a host whose libm fails tests/test_libm_pin.py) -- same results."""
+    _ensemble_batch_vs_oracles(pb, orc, 1, 1)
+
+
+def _ensemble_batch_vs_oracles(pb, orc, resident, min_distance_mode):
     """pbSimCreateBatch: 12 simulations that differ in seed, light position, noise level, obstacles
     and dead sets, stepped by the same launches, each bit-identical to its own oracle run -- through
     the initial sort, two phase updates and a forced re-sort schedule."""
@@ -332,6 +342,8 @@ def test_ensemble_batch_matches_individual_oracles(pb, orc, resident):
         osims.append(osim)
     ens = pb.Ensemble(members, keepalive=keep)
     ens.set_resident(resident)
+    from particlerobotsimulations_amd import _capi
+    _capi.check(_capi.lib().pbSimSetMinDistanceMode(ens._h, min_distance_mode))
     for k, osim in enumerate(osims):
         ens.set_state_of(k, pos=osim.get("pos"), vel=osim.get("vel"), rad=osim.get("rad"),
                          phase=osim.get("phase"), dead=osim.get("dead"))

@@ -80,6 +80,20 @@ def test_placement_with_buried_anchor_shortcut_matches_oracle(host, orc, cfg, n,
     assert_bit_equal(h.get("pos"), o.get("pos"), f"{cfg} at {n} bots: placement")
 
 
+@pytest.mark.parametrize("min_radius,max_radius,n,seed", [(1.0, 1.5, 1200, 8), (1.0, 1.5, 1500, 77), (0.7, 1.0, 2500, 77),
+                                                          (0.2, 0.3, 4000, 77)])
+def test_placement_in_a_rescaled_arena_matches_oracle(host, orc, min_radius, max_radius, n, seed):
+    """Big discs: once 2 (ring + limit) exceeds 5, an anchor's ring reaches the seed disc, which sits
+    at (5,0) but is FILED under the origin's cell (particlebot.cpp:635-637), where the reference's 3x3 crowded
+    test only finds it for candidates near the origin.  ringCovered must not count it as cover elsewhere.
+    (The first case is one found by search in which counting it changed the blob from bot 52 on.)"""
+    path = os.path.join(ROOT, "examples", "example.cfg")
+    kw = dict(nCells=n, seed=seed, min_radius=min_radius, max_radius=max_radius)
+    h = host.HostSim(path, engine="host", **{k: str(v) for k, v in kw.items()})
+    o = orc.Sim(orc.load_cfg(path, **kw), reset=True)
+    assert_bit_equal(h.get("pos"), o.get("pos"), f"min_radius {min_radius}: placement")
+
+
 def test_large_placement_matches_oracle(host, orc):
     """10^4 bots (BASELINE config 2b's scale): the accept/reject loop stays in lock-step."""
     path = os.path.join(ROOT, "examples", "example_dead_cells.cfg")
