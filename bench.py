@@ -144,11 +144,14 @@ def cpu_baseline(n_bots, pitch=LATTICE_PITCH, budget_s=12.0):
                       f"({el:.1f} s); reported, not optimised"}
 
 
+HEADLINE_VARIANT = 2   # the exact kernel; --force-variant 3 (profiling the streamlined kernel) is flagged in the line
+
+
 def make_sim(pb, n, pitch, seed, lattice="square"):
     import numpy as np
     sp, keep = workload_params(n, seed=seed)
     sim = pb.Sim(sp, wall_half=240.0, keepalive=keep)
-    sim.set_force_variant(2)   # the exact kernel, whatever the environment says (legs that want 3 set it)
+    sim.set_force_variant(HEADLINE_VARIANT)   # the exact kernel, whatever the environment says (legs that want 3 set it)
     sim.set_lanes_per_bot(0)
     sim.set_resident(0)
     pos = square_lattice(n, pitch) if lattice == "square" else hex_lattice(n, np.float32(pitch))
@@ -594,6 +597,10 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=100.0,
                     help="device time of scratch work before the measured simulation (clock ramp); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the cpu_baseline sample")
+    ap.add_argument("--force-variant", type=int, default=2, choices=[0, 1, 2, 3],
+                    help="force kernel of the arena workload (default 2, the exact kernel = the headline).  3 = the "
+                         "opt-in streamlined kernel: for profiling it with tools/profile.sh; the line then says "
+                         "`headline: false`")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path")
     args = ap.parse_args()
@@ -634,11 +641,13 @@ def main():
             dist.destroy_process_group()
         return
 
+    global HEADLINE_VARIANT
+    HEADLINE_VARIANT = args.force_variant
     n = args.bots
     warm = DevicePrewarm(pb, n, args.pitch, args.prewarm_ms)
     sim = make_sim(pb, n, args.pitch, seed=1 + rank)
     cfg = sim.config()
-    assert cfg["force_variant"] == 2, cfg  # `value` is always the exact kernel
+    assert cfg["force_variant"] == args.force_variant, cfg  # `value` is the exact kernel unless --force-variant says otherwise
 
     def barrier():
         sim.synchronize()
@@ -727,6 +736,7 @@ def main():
                                  "IEEE square roots -- one fewer since Sum|F_attr| is only kept when something reads it --, DESIGN.md section 5): `valu` prices its instruction stream at the "
                                  "datasheet issue rate at the measured shader clock and at tools/valu_rate's rates; "
                                  "`traffic` (PMC) ~ algorithmic bytes, i.e. no wasted re-reads"},
+            "headline": args.force_variant == 2,
             "device_ms_timed_region": dev_ms,
             "device_prewarm": prewarm,
             "summaries_time_comx_comy": summaries,

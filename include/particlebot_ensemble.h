@@ -37,6 +37,41 @@ int pbEnsembleSynchronize(void *ensemble);
 int pbEnsembleGetState(void *ensemble, int member, float *pos, float *vel, float *rad);
 unsigned pbEnsembleNumBots(void *ensemble);
 
+/* ---- pipelined form: host placement overlapped with device stepping --------------------------------------------
+ * The placement of a member is host work (the reference's CONFIG_RANDOM rule is O(N^1.5): 1.4 s for a 10^5-bot
+ * member; particlebot.cpp:612-748) and pbEnsembleCreate does all of it before the first launch.  The pipeline cuts
+ * the rank's members into sub-batches of `sub_batch` members (<= 0: one batch) and builds the members of sub-batch
+ * k+1 (k+2, ...) on `host_threads` producer threads (<= 0: the rank's share of the host cores minus one for the
+ * thread that drives the device) WHILE the device steps sub-batch k: wall time = max(host, device) + one
+ * sub-batch's placement instead of their sum.  Rows (and final states) do not depend on sub_batch or on the
+ * number of threads: every member draws from its own private random stream and every kernel form is
+ * bit-identical to the member's own CPU-oracle run (tests/test_gpu_ensemble_pipeline.py).
+ * Placement starts inside pbEnsemblePipelineCreate (it returns at once); Run may be called once:
+ * every member runs up to max_steps timesteps (or to max_time); out/max_rows/rows as pbEnsembleRun.
+ * keep_final_states: copy every member's final pos/vel/rad to the host as its sub-batch ends
+ * (pbEnsemblePipelineGetState).  Returns the timesteps per member, -1 on error. */
+typedef struct pbEnsembleTimings {
+  double wall_s;            /* the whole Run call: placement still outstanding + upload + steps + read-backs */
+  double placement_cpu_s;   /* CPU-seconds the producer threads spent building members (sum over threads) */
+  double placement_wait_s;  /* time the device-driving thread waited for members to be built (the device idles) */
+  double upload_s;          /* pbSimCreateBatch + state upload of all sub-batches */
+  double device_s;          /* stepping + summary rows (+ final-state read-back) of all sub-batches */
+  int sub_batches;
+  int sub_batch;            /* members per sub-batch as used */
+  int host_threads;         /* producer threads as used */
+} pbEnsembleTimings;
+void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
+                               int nmembers, int sub_batch, int host_threads, int keep_final_states);
+long pbEnsemblePipelineRun(void *pipeline, long max_steps, float *out, int max_rows, int *rows,
+                           pbEnsembleTimings *timings);
+void pbEnsemblePipelineDestroy(void *pipeline);
+unsigned pbEnsemblePipelineNumBots(void *pipeline);
+int pbEnsemblePipelineGetState(void *pipeline, int member, float *pos, float *vel, float *rad);
+/* The consumer side without a device (CPU tests): takes the sub-batches in order as Run does, records a checksum
+ * of every member's placed state instead of stepping it, dwells dwell_ms per sub-batch; *max_ahead = the most
+ * members ever claimed by producers beyond the consumed ones (bounded by 3 sub-batches). */
+int pbEnsemblePipelineDryRun(void *pipeline, int dwell_ms, unsigned long long *checksums, int *max_ahead);
+
 /* Number of members rank `rank` of `world` runs (members rank, rank + world, ...); block size per
  * rank in the gather = pbEnsembleShard(nmembers, 0, world). */
 int pbEnsembleShard(int nmembers, int rank, int world);

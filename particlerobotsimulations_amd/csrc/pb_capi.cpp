@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <climits>
+#include <condition_variable>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -308,107 +310,99 @@ void pbHostLibcRandDraws(unsigned seed, int n, int *out) {
 // Member k = the base .cfg + common overrides + its own overrides (typically "seed\n<k>").  The
 // host work of every member (random placement, dead-bot draw) runs in its own HostOnly Particlebot
 // with its own private libc-compatible stream; the device work of all members runs in ONE batched
-// pbSim, one launch per timestep.  Summaries (time, COMx, COMy, distance of COM to the light) are
+// pbSim, one launch per timestep.  Summaries (time, COMx, COMy, distance of the COM to the light) are
 // taken whenever a dump row would be due.
-struct Ensemble {
-  std::vector<PbRunConfig *> cfgs;
-  std::vector<Particlebot *> bots;
-  pbSim *sim = nullptr;
-  bool haveRow = false;  // pbEnsembleRunSteps: a summary row has been written at time rowTime
-  float rowTime = 0.0f;
-  ~Ensemble() {
-    if (sim) pbSimDestroy(sim);
-    for (auto *b : bots) delete b;
-    for (auto *c : cfgs) delete c;
+}  // extern "C"
+
+namespace {
+
+// one member: its resolved configuration and the HostOnly object that places it and draws its dead set
+struct Member {
+  PbRunConfig *cfg = nullptr;
+  Particlebot *bot = nullptr;
+  bool deadDrawn = false;  // the dead set was drawn with the placement (a draw due at time 0)
+  ~Member() {
+    delete bot;
+    delete cfg;
   }
 };
 
-void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
-                       int nmembers) {
-  if (nmembers < 1) return nullptr;
-  Ensemble *e = new Ensemble();
-  e->cfgs.assign(nmembers, nullptr);
-  e->bots.assign(nmembers, nullptr);
-  // Members are independent (own configuration, own private random stream, own placement grid):
-  // build them on all host cores.  The reference's random placement is O(N^1.5) (2.7 s for 10^5
-  // bots), so a sweep of large members would otherwise spend minutes here.
-  std::atomic<int> next{0};
-  std::atomic<bool> failed{false};
-  auto worker = [&]() {
-    for (int k = next++; k < nmembers && !failed; k = next++) {
-      PbRunConfig *cfg = new PbRunConfig();
-      cfg->params.seed = 0;
-      e->cfgs[k] = cfg;
-      if (cfg_path && !cfg->loadFile(cfg_path)) {
-        failed = true;
-        return;
-      }
-      applyOverrides(*cfg, common_overrides);
-      if (member_overrides) applyOverrides(*cfg, member_overrides[k]);
-      cfg->derive();
-      Particlebot *bot = new Particlebot(cfg->params, Particlebot::Engine::HostOnly, cfg->wallHalf());
-      bot->setHexSpacing(cfg->hex_spacing);
-      bot->setSquareLattice(cfg->square_lattice);
-      bot->setFastBlob(cfg->fast_blob);
-      bot->setRng(cfg->rng_kind);
-      bot->reset();
-      e->bots[k] = bot;
-    }
-  };
+// Host side of one member: configuration, placement (Particlebot::reset) and -- when the draw is due at the very
+// first step -- the dead set, all from the member's PRIVATE random stream, so that it does not matter which thread
+// builds which member, or when.  Returns false if the .cfg cannot be read.
+bool buildMember(Member &m, const char *cfg_path, const char *common_overrides, const char *own_overrides) {
+  m.cfg = new PbRunConfig();
+  m.cfg->params.seed = 0;
+  if (cfg_path && !m.cfg->loadFile(cfg_path)) return false;
+  applyOverrides(*m.cfg, common_overrides);
+  applyOverrides(*m.cfg, own_overrides);
+  m.cfg->derive();
+  Particlebot *bot = new Particlebot(m.cfg->params, Particlebot::Engine::HostOnly, m.cfg->wallHalf());
+  bot->setHexSpacing(m.cfg->hex_spacing);
+  bot->setSquareLattice(m.cfg->square_lattice);
+  bot->setFastBlob(m.cfg->fast_blob);
+  bot->setRng(m.cfg->rng_kind);
+  bot->reset();
+  bot->setHostTime(0.0f);
+  if (bot->deadDrawDue(m.cfg->timestep)) {  // particlebot.cpp:178: drawn at the top of the first update()
+    (void)bot->drawDeadBotsNow();
+    m.deadDrawn = true;
+  }
+  m.bot = bot;
+  return true;
+}
+
+// host threads for placement: all cores, shared between the ranks of a node (one process per GPU)
+unsigned hostThreads(int wanted) {
   unsigned nthreads = std::thread::hardware_concurrency();
-  // one process per GPU: share the host's cores between the ranks of this node
   for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE"})
     if (const char *v = getenv(name)) {
       if (atoi(v) > 1) nthreads = std::max(1u, nthreads / (unsigned)atoi(v));
       break;
     }
   if (const char *v = getenv("PB_HOST_THREADS")) nthreads = (unsigned)atoi(v);
+  if (wanted > 0) nthreads = (unsigned)wanted;
   cpu_set_t set;
-  if (sched_getaffinity(0, sizeof set, &set) == 0) nthreads = std::min<unsigned>(nthreads, (unsigned)CPU_COUNT(&set));
-  nthreads = std::max(1u, std::min<unsigned>(std::min(nthreads, 128u), (unsigned)nmembers));
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker);
-  worker();
-  for (auto &th : pool) th.join();
-  if (failed) {
-    delete e;
-    return nullptr;
-  }
-  std::vector<SimParams> params;
-  for (int k = 0; k < nmembers; k++) params.push_back(e->bots[k]->getParams());
-  if (pbSimCreateBatch(&e->sim, params.data(), nmembers, e->cfgs[0]->wallHalf()) != PB_OK) {
-    fprintf(stderr, "pbEnsembleCreate: %s\n", pbGetLastErrorString());
-    delete e;
-    return nullptr;
-  }
-  if (e->cfgs[0]->rng_kind != 0 && pbSimSetRng(e->sim, e->cfgs[0]->rng_kind) != PB_OK) {
-    fprintf(stderr, "pbEnsembleCreate: %s\n", pbGetLastErrorString());
-    delete e;
-    return nullptr;
-  }
-  for (int k = 0; k < nmembers; k++) {
-    Particlebot *b = e->bots[k];
-    if (pbSimSetStateOf(e->sim, (unsigned)k, b->hostPositions(), b->hostVelocities(), b->hostRadii(),
-                        b->hostPhases(), b->hostDead()) != PB_OK) {
-      fprintf(stderr, "pbEnsembleCreate: %s\n", pbGetLastErrorString());
-      delete e;
-      return nullptr;
-    }
-  }
-  return e;
+  if (sched_getaffinity(0, sizeof set, &set) == 0 && wanted <= 0)
+    nthreads = std::min<unsigned>(nthreads, (unsigned)CPU_COUNT(&set));
+  return std::max(1u, std::min(nthreads, 128u));
 }
 
-void pbEnsembleDestroy(void *ev) { delete (Ensemble *)ev; }
+// A batch of members on the device: ONE pbSim, one launch per timestep.
+struct Ensemble {
+  std::vector<Member *> members;  // owned
+  pbSim *sim = nullptr;
+  bool haveRow = false;  // runSteps: a summary row has been written at time rowTime
+  float rowTime = 0.0f;
+  ~Ensemble() {
+    if (sim) pbSimDestroy(sim);
+    for (auto *m : members) delete m;
+  }
+};
 
-// Runs every member for up to max_steps timesteps (or to max_time, whichever comes first) and can be
-// called again to continue.  out: [nmembers][max_rows][4] floats (time, COMx, COMy, distance of the
-// COM to the light), one row whenever a dump row would be due (particlebot.cpp:309); *rows counts
-// the rows written per member so far (the same for all members) and is carried between calls.
-// Returns the number of timesteps executed by this call, or -1 on error.
-long pbEnsembleRunSteps(void *ev, long max_steps, float *out, int max_rows, int *rows) {
-  Ensemble *e = (Ensemble *)ev;
-  const int m = (int)e->bots.size();
-  const PbRunConfig &c0 = *e->cfgs[0];
+// device side: create the batched pbSim of already built members and upload their initial state
+bool uploadEnsemble(Ensemble *e) {
+  const int nmembers = (int)e->members.size();
+  std::vector<SimParams> params;
+  for (int k = 0; k < nmembers; k++) params.push_back(e->members[k]->bot->getParams());
+  const PbRunConfig &c0 = *e->members[0]->cfg;
+  if (pbSimCreateBatch(&e->sim, params.data(), nmembers, c0.wallHalf()) != PB_OK) return false;
+  if (c0.rng_kind != 0 && pbSimSetRng(e->sim, c0.rng_kind) != PB_OK) return false;
+  for (int k = 0; k < nmembers; k++) {
+    Particlebot *b = e->members[k]->bot;
+    if (pbSimSetStateOf(e->sim, (unsigned)k, b->hostPositions(), b->hostVelocities(), b->hostRadii(), b->hostPhases(),
+                        b->hostDead()) != PB_OK)
+      return false;
+  }
+  return true;
+}
+
+// Runs every member of the batch for up to max_steps timesteps (or to max_time, whichever comes first); can be
+// called again to continue.  Row r of member k goes to out[(k * max_rows + r) * 4 ..]: (time, COMx, COMy, distance
+// of the COM to the light), one row whenever a dump row would be due (particlebot.cpp:309).
+long runSteps(Ensemble *e, long max_steps, float *out, int max_rows, int *rows) {
+  const int m = (int)e->members.size();
+  const PbRunConfig &c0 = *e->members[0]->cfg;
   const float dt = c0.timestep, di = c0.dump_interval;
   std::vector<double> com(2 * (size_t)m);
   long steps = 0;
@@ -421,7 +415,7 @@ long pbEnsembleRunSteps(void *ev, long max_steps, float *out, int max_rows, int 
     if (out && !(t - di * floorf(t / di) > 0.01f) && nrows < max_rows && !(e->haveRow && e->rowTime == t)) {
       if (pbSimCentroids(e->sim, com.data()) != PB_OK) return -1;
       for (int k = 0; k < m; k++) {
-        const SimParams &p = e->bots[k]->getParams();
+        const SimParams &p = e->members[k]->bot->getParams();
         float *row = out + ((size_t)k * max_rows + nrows) * 4;
         const double dx = com[2 * k] - p.light_x, dy = com[2 * k + 1] - p.light_y;
         row[0] = t;
@@ -434,11 +428,13 @@ long pbEnsembleRunSteps(void *ev, long max_steps, float *out, int max_rows, int 
       e->rowTime = t;
     }
     if (t > c0.params.max_time || steps >= max_steps) break;
-    // host events at this step: dead-bot draws
+    // host events at this step: dead-bot draws (those due at time 0 came with the placement)
     for (int k = 0; k < m; k++) {
-      Particlebot *b = e->bots[k];
+      Member *mk = e->members[k];
+      Particlebot *b = mk->bot;
       b->setHostTime(t);
-      if (b->deadDrawDue(dt)) {
+      if (b->deadDrawDue(dt) && !mk->deadDrawn) {
+        mk->deadDrawn = true;
         if (pbSimSetStateOf(e->sim, (unsigned)k, nullptr, nullptr, nullptr, nullptr, b->drawDeadBotsNow()) != PB_OK)
           return -1;
       }
@@ -450,8 +446,8 @@ long pbEnsembleRunSteps(void *ev, long max_steps, float *out, int max_rows, int 
       bool stop = !(tt - di * floorf(tt / di) > 0.01f) || tt > c0.params.max_time || run >= (1 << 20) ||
                   steps + run >= max_steps;
       for (int k = 0; k < m && !stop; k++) {
-        e->bots[k]->setHostTime(tt);
-        stop = e->bots[k]->deadDrawDue(dt);
+        e->members[k]->bot->setHostTime(tt);
+        stop = e->members[k]->bot->deadDrawDue(dt);
       }
       if (stop) break;
       tt = tt + dt;
@@ -467,12 +463,301 @@ long pbEnsembleRunSteps(void *ev, long max_steps, float *out, int max_rows, int 
   return steps;
 }
 
+double nowSeconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- the pipelined form: host placement of sub-batch k+1 overlapped with device stepping of sub-batch k --------
+// A rank's members are cut into sub-batches of `sub` members (in member order).  A pool of producer threads builds
+// members in order (configuration, placement, early dead draw), never more than `ahead` sub-batches beyond the one
+// on the device; the calling thread takes the sub-batches in order: waits until its members are built, creates the
+// batched pbSim, uploads, steps it to the end, keeps what was asked for, frees it.  A member's trajectory does not
+// depend on which members share its batch (every kernel form is bit-identical to the member's own oracle run; the
+// centroid is a fixed-order per-member reduction), so the rows are independent of `sub`
+// (tests/test_gpu_ensemble_pipeline.py).
+struct Pipeline {
+  std::string cfgPath, common;
+  bool haveCfg = false;
+  std::vector<std::string> over;
+  int nmembers = 0, sub = 0, threads = 1, ahead = 2;
+  bool keepStates = false;
+  std::vector<Member *> built;  // [nmembers], filled by the producers, taken by the consumer
+  std::vector<char> ready;
+  std::mutex mu;
+  std::condition_variable cvReady, cvRoom;
+  int nextToBuild = 0, consumedUpTo = 0;  // members < consumedUpTo have been taken by the consumer
+  bool failed = false, stop = false;
+  std::vector<std::thread> pool;
+  std::vector<std::vector<float>> finalPos, finalVel, finalRad;
+  unsigned nbots = 0;
+  pbEnsembleTimings tm{};
+  std::vector<double> cpuSeconds;  // per producer thread
+
+  void producer(int tid) {
+    for (;;) {
+      int k;
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        // room: at most `ahead` sub-batches beyond the one the consumer is on
+        cvRoom.wait(lock, [&] { return stop || failed || nextToBuild >= nmembers || nextToBuild < consumedUpTo + (ahead + 1) * sub; });
+        if (stop || failed || nextToBuild >= nmembers) return;
+        k = nextToBuild++;
+      }
+      const double t0 = nowSeconds();
+      Member *m = new Member();
+      const bool ok = buildMember(*m, haveCfg ? cfgPath.c_str() : nullptr, common.empty() ? nullptr : common.c_str(),
+                                  over[k].c_str());
+      cpuSeconds[tid] += nowSeconds() - t0;
+      std::lock_guard<std::mutex> lock(mu);
+      if (!ok) {
+        delete m;
+        failed = true;
+      } else {
+        built[k] = m;
+        ready[k] = 1;
+      }
+      cvReady.notify_all();
+      cvRoom.notify_all();
+    }
+  }
+  void start() {
+    cpuSeconds.assign(threads, 0.0);
+    for (int t = 0; t < threads; t++) pool.emplace_back(&Pipeline::producer, this, t);
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      stop = true;
+    }
+    cvRoom.notify_all();
+    cvReady.notify_all();
+    for (auto &th : pool) th.join();
+    pool.clear();
+    for (auto *&m : built) {
+      delete m;
+      m = nullptr;
+    }
+  }
+  ~Pipeline() { shutdown(); }
+};
+
+}  // namespace
+
+extern "C" {
+
+void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
+                       int nmembers) {
+  if (nmembers < 1) return nullptr;
+  Ensemble *e = new Ensemble();
+  e->members.assign(nmembers, nullptr);
+  // Members are independent (own configuration, own private random stream, own placement grid):
+  // build them on all host cores.  The reference's random placement is O(N^1.5) (1.4 s for 10^5
+  // bots), so a sweep of large members would otherwise spend minutes here.  (pbEnsemblePipeline* overlaps
+  // this with the device work of the members built before.)
+  std::atomic<int> next{0};
+  std::atomic<bool> failed{false};
+  auto worker = [&]() {
+    for (int k = next++; k < nmembers && !failed; k = next++) {
+      Member *m = new Member();
+      e->members[k] = m;
+      if (!buildMember(*m, cfg_path, common_overrides, member_overrides ? member_overrides[k] : nullptr)) failed = true;
+    }
+  };
+  const unsigned nthreads = std::min<unsigned>(hostThreads(0), (unsigned)nmembers);
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker);
+  worker();
+  for (auto &th : pool) th.join();
+  if (failed) {
+    delete e;
+    return nullptr;
+  }
+  if (!uploadEnsemble(e)) {
+    fprintf(stderr, "pbEnsembleCreate: %s\n", pbGetLastErrorString());
+    delete e;
+    return nullptr;
+  }
+  return e;
+}
+
+void pbEnsembleDestroy(void *ev) { delete (Ensemble *)ev; }
+
+// Runs every member for up to max_steps timesteps (or to max_time, whichever comes first) and can be
+// called again to continue.  out: [nmembers][max_rows][4] floats (time, COMx, COMy, distance of the
+// COM to the light), one row whenever a dump row would be due (particlebot.cpp:309); *rows counts
+// the rows written per member so far (the same for all members) and is carried between calls.
+// Returns the number of timesteps executed by this call, or -1 on error.
+long pbEnsembleRunSteps(void *ev, long max_steps, float *out, int max_rows, int *rows) {
+  return runSteps((Ensemble *)ev, max_steps, out, max_rows, rows);
+}
+
 // Runs every member to max_time (the whole run in one call).
 long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
   int nrows = 0;
   const long steps = pbEnsembleRunSteps(ev, LONG_MAX, out, max_rows, &nrows);
   if (rows) *rows = nrows;
   return steps;
+}
+
+// ---- pipelined ensembles (include/particlebot_ensemble.h) ------------------------------------------------------
+void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
+                               int nmembers, int sub_batch, int host_threads, int keep_final_states) {
+  if (nmembers < 1) return nullptr;
+  Pipeline *p = new Pipeline();
+  p->haveCfg = cfg_path != nullptr;
+  if (cfg_path) p->cfgPath = cfg_path;
+  if (common_overrides) p->common = common_overrides;
+  for (int k = 0; k < nmembers; k++) p->over.emplace_back(member_overrides && member_overrides[k] ? member_overrides[k] : "");
+  p->nmembers = nmembers;
+  p->sub = (sub_batch < 1 || sub_batch > nmembers) ? nmembers : sub_batch;
+  // the calling thread drives the device: leave it a core when there are several
+  const unsigned avail = hostThreads(host_threads);
+  p->threads = (int)std::max(1u, std::min<unsigned>(host_threads > 0 ? avail : (avail > 1 ? avail - 1 : 1), (unsigned)nmembers));
+  p->keepStates = keep_final_states != 0;
+  p->built.assign(nmembers, nullptr);
+  p->ready.assign(nmembers, 0);
+  if (p->keepStates) {
+    p->finalPos.resize(nmembers);
+    p->finalVel.resize(nmembers);
+    p->finalRad.resize(nmembers);
+  }
+  p->tm.host_threads = p->threads;
+  p->tm.sub_batch = p->sub;
+  p->start();  // placement starts now, before the caller asks for the first step
+  return p;
+}
+
+void pbEnsemblePipelineDestroy(void *pv) { delete (Pipeline *)pv; }
+
+long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, int *rows, pbEnsembleTimings *timings) {
+  Pipeline *p = (Pipeline *)pv;
+  if (!p || p->consumedUpTo != 0) return -1;  // one run per pipeline
+  const double t0 = nowSeconds();
+  long steps = 0;
+  int nrowsAll = 0;
+  for (int first = 0; first < p->nmembers; first += p->sub) {
+    const int count = std::min(p->sub, p->nmembers - first);
+    Ensemble e;
+    {
+      const double w0 = nowSeconds();
+      std::unique_lock<std::mutex> lock(p->mu);
+      p->cvReady.wait(lock, [&] {
+        if (p->failed) return true;
+        for (int k = first; k < first + count; k++)
+          if (!p->ready[k]) return false;
+        return true;
+      });
+      if (p->failed) return -1;
+      for (int k = first; k < first + count; k++) {
+        e.members.push_back(p->built[k]);
+        p->built[k] = nullptr;
+      }
+      p->consumedUpTo = first + count;
+      p->tm.placement_wait_s += nowSeconds() - w0;
+    }
+    p->cvRoom.notify_all();
+    const double u0 = nowSeconds();
+    if (!uploadEnsemble(&e)) {
+      fprintf(stderr, "pbEnsemblePipelineRun: %s\n", pbGetLastErrorString());
+      return -1;
+    }
+    p->nbots = e.members[0]->bot->getParams().nCells;
+    const double d0 = nowSeconds();
+    p->tm.upload_s += d0 - u0;
+    int nrows = 0;
+    const long done = runSteps(&e, max_steps, out ? out + (size_t)first * max_rows * 4 : nullptr, max_rows, &nrows);
+    if (done < 0 || pbSimSynchronize(e.sim) != PB_OK) return -1;
+    if (p->keepStates)
+      for (int k = 0; k < count; k++) {
+        const size_t n = p->nbots;
+        p->finalPos[first + k].resize(2 * n);
+        p->finalVel[first + k].resize(2 * n);
+        p->finalRad[first + k].resize(n);
+        if (pbSimGetStateOf(e.sim, (unsigned)k, p->finalPos[first + k].data(), p->finalVel[first + k].data(),
+                            p->finalRad[first + k].data(), nullptr, nullptr, nullptr, nullptr) != PB_OK)
+          return -1;
+      }
+    p->tm.device_s += nowSeconds() - d0;
+    if (first == 0) {
+      steps = done;
+      nrowsAll = nrows;
+    } else if (done != steps || nrows != nrowsAll) {
+      fprintf(stderr, "pbEnsemblePipelineRun: sub-batches disagree on the step or row count (%ld/%d vs %ld/%d)\n", done,
+              nrows, steps, nrowsAll);
+      return -1;
+    }
+    p->tm.sub_batches++;
+  }  // (~Ensemble frees the sub-batch's device memory and its members)
+  p->tm.wall_s = nowSeconds() - t0;
+  p->tm.placement_cpu_s = 0.0;
+  for (double c : p->cpuSeconds) p->tm.placement_cpu_s += c;
+  if (rows) *rows = nrowsAll;
+  if (timings) *timings = p->tm;
+  return steps;
+}
+
+// The consumer side WITHOUT a device (CPU tests of the pipeline's ordering): takes the sub-batches in order exactly
+// as Run does, and instead of stepping them records, per member, a checksum of the placed state (positions, radii,
+// dead flags) and dwells `dwell_ms` per sub-batch so that the producers run into the look-ahead bound.  *max_ahead
+// receives the largest number of members that were ever claimed by producers beyond the consumed ones.
+int pbEnsemblePipelineDryRun(void *pv, int dwell_ms, unsigned long long *checksums, int *max_ahead) {
+  Pipeline *p = (Pipeline *)pv;
+  if (!p || p->consumedUpTo != 0 || !checksums) return -1;
+  int worst = 0;
+  for (int first = 0; first < p->nmembers; first += p->sub) {
+    const int count = std::min(p->sub, p->nmembers - first);
+    std::vector<Member *> mine;
+    {
+      std::unique_lock<std::mutex> lock(p->mu);
+      p->cvReady.wait(lock, [&] {
+        if (p->failed) return true;
+        for (int k = first; k < first + count; k++)
+          if (!p->ready[k]) return false;
+        return true;
+      });
+      if (p->failed) return -1;
+      worst = std::max(worst, p->nextToBuild - p->consumedUpTo);
+      for (int k = first; k < first + count; k++) {
+        mine.push_back(p->built[k]);
+        p->built[k] = nullptr;
+      }
+      p->consumedUpTo = first + count;
+    }
+    p->cvRoom.notify_all();
+    for (int k = 0; k < count; k++) {
+      const Particlebot *b = mine[k]->bot;
+      const size_t n = b->getParams().nCells;
+      unsigned long long h = 1469598103934665603ull;
+      auto mix = [&](const void *data, size_t bytes) {
+        const unsigned char *c = (const unsigned char *)data;
+        for (size_t i = 0; i < bytes; i++) h = (h ^ c[i]) * 1099511628211ull;
+      };
+      mix(b->hostPositions(), 8 * n);
+      mix(b->hostRadii(), 4 * n);
+      mix(b->hostDead(), 4 * n);
+      checksums[first + k] = h;
+      delete mine[k];
+    }
+    if (dwell_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(dwell_ms));
+    {
+      std::lock_guard<std::mutex> lock(p->mu);
+      worst = std::max(worst, p->nextToBuild - p->consumedUpTo);
+    }
+  }
+  if (max_ahead) *max_ahead = worst;
+  return 0;
+}
+
+unsigned pbEnsemblePipelineNumBots(void *pv) { return ((Pipeline *)pv)->nbots; }
+
+int pbEnsemblePipelineGetState(void *pv, int member, float *pos, float *vel, float *rad) {
+  Pipeline *p = (Pipeline *)pv;
+  if (!p || !p->keepStates || member < 0 || member >= p->nmembers || p->finalRad[member].empty()) return 1;
+  const size_t n = p->nbots;
+  if (pos) memcpy(pos, p->finalPos[member].data(), 8 * n);
+  if (vel) memcpy(vel, p->finalVel[member].data(), 8 * n);
+  if (rad) memcpy(rad, p->finalRad[member].data(), 4 * n);
+  return 0;
 }
 
 int pbEnsembleSynchronize(void *ev) { return pbSimSynchronize(((Ensemble *)ev)->sim); }
@@ -500,7 +785,7 @@ int pbEnsembleGetState(void *ev, int member, float *pos, float *vel, float *rad)
   return pbSimGetStateOf(e->sim, (unsigned)member, pos, vel, rad, nullptr, nullptr, nullptr, nullptr);
 }
 
-unsigned pbEnsembleNumBots(void *ev) { return ((Ensemble *)ev)->bots[0]->getParams().nCells; }
+unsigned pbEnsembleNumBots(void *ev) { return ((Ensemble *)ev)->members[0]->bot->getParams().nCells; }
 
 // ---- the libm properties the phase update rests on (pbSimSetMinDistanceMode 0) ---------------------
 // The engine returns min_i (dx*dx + dy*dy) from the device and takes powf(., 0.5f) on the host, where the

@@ -113,6 +113,102 @@ class LocalEnsemble:
             pass
 
 
+class Timings(C.Structure):
+    """pbEnsembleTimings (include/particlebot_ensemble.h)."""
+    _fields_ = [("wall_s", C.c_double), ("placement_cpu_s", C.c_double), ("placement_wait_s", C.c_double),
+                ("upload_s", C.c_double), ("device_s", C.c_double), ("sub_batches", C.c_int), ("sub_batch", C.c_int),
+                ("host_threads", C.c_int)]
+
+
+def _pipeline_lib():
+    from . import host
+    L = host.lib()
+    L.pbEnsemblePipelineCreate.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int,
+                                           C.c_int]
+    L.pbEnsemblePipelineCreate.restype = C.c_void_p
+    L.pbEnsemblePipelineRun.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                                        C.POINTER(Timings)]
+    L.pbEnsemblePipelineRun.restype = C.c_long
+    L.pbEnsemblePipelineDestroy.argtypes = [C.c_void_p]
+    L.pbEnsemblePipelineNumBots.argtypes = [C.c_void_p]
+    L.pbEnsemblePipelineNumBots.restype = C.c_uint
+    L.pbEnsemblePipelineGetState.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pbEnsemblePipelineDryRun.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    return L
+
+
+class PipelinedEnsemble:
+    """The members this rank runs, cut into sub-batches of `sub_batch` members: the host places sub-batch k+1 on
+    `host_threads` producer threads while the device steps sub-batch k (pbEnsemblePipeline* in csrc/pb_capi.cpp).
+    Placement starts in the constructor.  Rows and final states do not depend on sub_batch or host_threads."""
+
+    def __init__(self, cfg_path, overrides_per_member, common=None, sub_batch=0, host_threads=0, max_rows=4096,
+                 keep_final_states=False):
+        self._L = _pipeline_lib()
+        self.m = len(overrides_per_member)
+        self.max_rows = max_rows
+        self.out = np.zeros((self.m, max_rows, 4), np.float32)
+        self._rows = C.c_int(0)
+        self.timings = None
+        self._h = None
+        if self.m == 0:
+            return
+        arr = (C.c_char_p * self.m)(*[o.encode() for o in overrides_per_member])
+        common_b = "\n".join(f"{k}\n{v}" for k, v in (common or {}).items()).encode() or None
+        self._h = self._L.pbEnsemblePipelineCreate(os.fsencode(cfg_path), common_b, arr, self.m, int(sub_batch),
+                                                   int(host_threads), 1 if keep_final_states else 0)
+        if not self._h:
+            raise RuntimeError("pbEnsemblePipelineCreate failed")
+
+    def run(self, max_steps=2 ** 62):
+        """Every member up to max_steps timesteps (or to max_time); returns the timesteps per member."""
+        if self._h is None:
+            return 0
+        tm = Timings()
+        steps = self._L.pbEnsemblePipelineRun(self._h, int(max_steps), self.out.ctypes.data_as(C.c_void_p),
+                                              self.max_rows, C.byref(self._rows), C.byref(tm))
+        if steps < 0:
+            raise RuntimeError("pbEnsemblePipelineRun failed")
+        self.timings = {k: getattr(tm, k) for k, _ in Timings._fields_}
+        self.n = int(self._L.pbEnsemblePipelineNumBots(self._h))
+        return int(steps)
+
+    def dry_run(self, dwell_ms=0):
+        """CPU-only: the pipeline's consumer without a device.  Returns (checksums[m] of the placed members,
+        the most members ever claimed by the producers beyond the consumed ones)."""
+        sums = np.zeros(self.m, np.uint64)
+        ahead = C.c_int(0)
+        if self._L.pbEnsemblePipelineDryRun(self._h, int(dwell_ms), sums.ctypes.data_as(C.c_void_p), C.byref(ahead)):
+            raise RuntimeError("pbEnsemblePipelineDryRun failed")
+        return sums, ahead.value
+
+    @property
+    def rows(self):
+        return self.out[:, :self._rows.value].copy()
+
+    def final_states(self):
+        states = []
+        for k in range(self.m):
+            st = {"pos": np.empty((self.n, 2), np.float32), "vel": np.empty((self.n, 2), np.float32),
+                  "rad": np.empty(self.n, np.float32)}
+            if self._L.pbEnsemblePipelineGetState(self._h, k, *[st[x].ctypes.data_as(C.c_void_p)
+                                                                for x in ("pos", "vel", "rad")]):
+                raise RuntimeError("pbEnsemblePipelineGetState failed (keep_final_states not set?)")
+            states.append(st)
+        return states
+
+    def close(self):
+        if self._h is not None:
+            self._L.pbEnsemblePipelineDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def run_local(cfg_path, overrides_per_member, common=None, max_rows=4096, final_state=False):
     """Run the given members (a list of override strings) as one batch on the current GPU.
     Returns (rows[m, r, 4] float32, steps), plus a list of per-member dicts (pos, vel, rad at the

@@ -1,0 +1,73 @@
+"""CPU tests of the ensemble pipeline's host side (csrc/pb_capi.cpp, include/particlebot_ensemble.h): the producer
+pool builds members in order with a bounded look-ahead, the consumer takes sub-batches in order, and what a member
+looks like does not depend on the sub-batch size or on the number of producer threads (each member draws from its
+own private glibc-compatible stream; placement per /root/reference particlebot.cpp:612-748)."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "examples", "example_dead_cells.cfg")
+
+
+def _members(m):
+    # nDead > 0 with time_to_dead 0: the dead set is drawn with the placement
+    return [f"seed\n{1000 + k}\nnDead\n{5 + k}" for k in range(m)]
+
+
+def _dry(sub, threads, m=23, dwell=0, common=None):
+    from particlerobotsimulations_amd.ensemble import PipelinedEnsemble
+    p = PipelinedEnsemble(CFG, _members(m), common or {"nCells": "400"}, sub_batch=sub, host_threads=threads)
+    sums, ahead = p.dry_run(dwell)
+    p.close()
+    return sums, ahead
+
+
+def test_members_do_not_depend_on_split_or_threads():
+    ref, _ = _dry(0, 1)
+    assert len(set(ref.tolist())) == len(ref)          # different seeds: different blobs
+    for sub, threads in ((1, 1), (4, 3), (8, 8), (5, 2), (23, 4), (100, 2)):
+        sums, _ = _dry(sub, threads)
+        assert np.array_equal(sums, ref), (sub, threads)
+
+
+def test_members_equal_the_one_batch_form(orc):
+    """The same members through the oracle's placement + dead draw: the pipeline's members are the reference's."""
+    sums, _ = _dry(3, 2, m=5)
+    import hashlib  # noqa: F401  (FNV below, as the C side)
+
+    def fnv(*arrays):
+        h = 1469598103934665603
+        for a in arrays:
+            for b in np.ascontiguousarray(a).view(np.uint8).reshape(-1).tolist():
+                h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    for k in range(5):
+        P = orc.load_cfg(CFG, nCells=400, seed=1000 + k, nDead=5 + k)
+        o = orc.Sim(P, reset=True)
+        o.run(0) if hasattr(o, "run") else None
+        dead = o.get("dead").copy()
+        if not dead.any():          # the oracle draws at the top of its first step; placement state otherwise equal
+            o2 = orc.Sim(P, reset=True)
+            o2.run(1)
+            dead = o2.get("dead")
+            o2.close()
+        assert int(sums[k]) == fnv(o.get("pos"), o.get("rad"), dead.astype(np.int32)), k
+        o.close()
+
+
+def test_look_ahead_is_bounded():
+    """Producers never claim more than (ahead + 1) = 3 sub-batches beyond what the consumer has taken."""
+    for sub, threads in ((2, 4), (4, 8)):
+        _, ahead = _dry(sub, threads, m=40, dwell=5, common={"nCells": "150"})
+        assert ahead <= 3 * sub, (sub, threads, ahead)
+        assert ahead >= sub          # ... and they do run ahead while the consumer dwells
+
+
+def test_bad_cfg_fails_cleanly():
+    from particlerobotsimulations_amd.ensemble import PipelinedEnsemble
+    p = PipelinedEnsemble(os.path.join(ROOT, "examples", "no_such.cfg"), _members(3), None, sub_batch=2, host_threads=2)
+    with pytest.raises(RuntimeError):
+        p.dry_run()
+    p.close()

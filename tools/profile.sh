@@ -1,10 +1,10 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel trace + three separate PMC passes of the
 # bench workload, raw output under gpurun_out/prof_<tag>/, then a distilled summary next to it.
-# usage: tools/profile.sh <tag> [bench args...]
+# usage: tools/profile.sh <tag> [bench args...]      (PB_PROFILE_VARIANT=3: profile the streamlined kernel)
 set -u
 TAG=${1:-run}; shift || true
-ARGS=${@:---steps 400 --warmup 100 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg --no-both-sums}
+ARGS=${@:---force-variant ${PB_PROFILE_VARIANT:-2} --steps 400 --warmup 100 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg --no-both-sums}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
