@@ -160,6 +160,37 @@ def make_sim(pb, n, pitch, seed, lattice="square"):
     return sim
 
 
+LONG_MS = 100.0    # a timed region shorter than SHORT_MS of device time is followed by a second one of >= LONG_MS
+SHORT_MS = 50.0
+
+
+def timed_leg(sim, warm, warmup, steps):
+    """The measurement protocol of every arena leg: >= 100 ms of the same kind of work on the
+    scratch arena IMMEDIATELY before (clock ramp), W untimed warm-up steps, EXACTLY K timed steps between HIP
+    events on the simulation's stream -- nothing else in between, no host copy, no allocation -- and, when those K
+    steps were less than 50 ms of device time (the driver's --steps 20 is ~2 ms), a second region of >= 100 ms
+    right behind it, reported as *_long."""
+    prewarm = warm.run() if warm is not None else None
+    sim.step(warmup)
+    done, ms = sim.step_timed(steps)
+    out = {"steps": done, "ms": ms, "us_per_step": ms * 1e3 / max(done, 1), "device_prewarm_ms": prewarm["ms"] if prewarm else 0.0}
+    if ms < SHORT_MS and done > 0:
+        k = min(int(LONG_MS / max(ms / done, 1e-6)) + 1, 400000)
+        d2, ms2 = sim.step_timed(k)
+        out.update(steps_long=d2, ms_long=ms2, us_per_step_long=ms2 * 1e3 / max(d2, 1))
+    return out
+
+
+def leg_fields(t, n):
+    """value / us_per_step (+ *_long) of a timed_leg result for an n-bot arena."""
+    f = {"value": n * t["steps"] / (t["ms"] * 1e-3), "unit": "particle-steps/s (device time)", "steps": t["steps"],
+         "us_per_step": t["us_per_step"], "device_prewarm_ms": t["device_prewarm_ms"]}
+    if "ms_long" in t:
+        f.update(value_long=n * t["steps_long"] / (t["ms_long"] * 1e-3), steps_long=t["steps_long"],
+                 us_per_step_long=t["us_per_step_long"])
+    return f
+
+
 def survey_literal(pb, n, steps, warmup):
     """The hexagonal lattice exactly as SURVEY.md 8(d) words it, reported beside the headline."""
     sim = make_sim(pb, n, LATTICE_PITCH, seed=1, lattice="hex")
@@ -178,59 +209,71 @@ def survey_literal(pb, n, steps, warmup):
                     "(see the LATTICE_PITCH comment in bench.py)"}
 
 
-def streamlined_leg(pb, n, pitch, steps, warmup):
+def streamlined_leg(pb, n, pitch, steps, warmup, warm=None):
     """The opt-in streamlined force arithmetic (force variant 3; NOT bit-identical, DESIGN.md
-    "Streamlined") on the same workload: its deviation from the exact kernel over one 10-step window
-    from the same state, then its throughput over `steps` steps (device time, HIP events)."""
+    "Streamlined") on the same workload: its throughput over `steps` steps (device time, HIP events; pre-warmed,
+    nothing between warm-up and timing), THEN its deviation from the exact kernel over one 10-step window from a
+    common state."""
     import numpy as np
-    exact, fast = make_sim(pb, n, pitch, seed=1), make_sim(pb, n, pitch, seed=1)
-    for s in (exact, fast):
-        s.set_force_variant(2)
-        s.step(warmup)
+    fast = make_sim(pb, n, pitch, seed=1)
     fast.set_force_variant(3)
+    t = timed_leg(fast, warm, warmup, steps)
+    cx, cy = fast.centroid()
+    # parity window: both kernels from the state the timed run ended in
+    st = fast.get_state()
+    ta = fast.time
+    exact, fast2 = make_sim(pb, n, pitch, seed=1), make_sim(pb, n, pitch, seed=1)
+    for sim, variant in ((exact, 2), (fast2, 3)):
+        # (a fresh simulation object has no cell lists yet: both copies re-sort at their first step, from the
+        #  same positions)
+        sim.set_state(pos=st["pos"], vel=st["vel"], rad=st["rad"], phase=st["phase"], dead=st["dead"])
+        sim.set_forces(st["absForce_a"] if st["absForce_a"] is not None else np.zeros(n, np.float32), st["absForce_r"])
+        sim.time = ta
+        sim.set_force_variant(variant)
+    fast.close()
     exact.step(10)
-    fast.step(10)
-    a, b = exact.get_state()["pos"].astype(np.float64), fast.get_state()["pos"].astype(np.float64)
+    fast2.step(10)
+    a, b = exact.get_state()["pos"].astype(np.float64), fast2.get_state()["pos"].astype(np.float64)
     exact.close()
+    fast2.close()
     d = np.linalg.norm(b - a, axis=1)
     rel = d / np.maximum(np.linalg.norm(a, axis=1), 1.0)
     com = float(np.linalg.norm(a.mean(0) - b.mean(0)))
-    done, ms = fast.step_timed(steps)
-    cx, cy = fast.centroid()
-    fast.close()
-    achieved = ALG_BYTES_PER_PARTICLE_STEP * n * done / (ms * 1e-3) / 1e9
-    return {"value": n * done / (ms * 1e-3), "unit": "particle-steps/s (device time)", "steps": done,
-            "ms_per_step": ms / max(done, 1), "finite_at_end": bool(cx == cx and cy == cy),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "kernel": "k_force_stream<FUSE>"},
-            "parity": {"against": f"the exact kernel from the same state after {warmup} steps; the exact kernel is "
+    out = leg_fields(t, n)
+    us = out.get("us_per_step_long", out["us_per_step"])
+    achieved = ALG_BYTES_PER_PARTICLE_STEP * n / (us * 1e-6) / 1e9
+    out.update({"ms_per_step": out["us_per_step"] * 1e-3, "finite_at_end": bool(cx == cx and cy == cy),
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "kernel": "k_force_stream",
+                         "over": "us_per_step_long" if "us_per_step_long" in out else "us_per_step"},
+            "parity": {"against": "the exact kernel over 10 steps from the state the timed run ended in; the exact kernel is "
                                   "bit-identical to the CPU oracle on this very workload "
-                                  "(tests/test_gpu_baseline_configs.py::test_bench_headline_workload_matches_oracle), so "
-                                  "these are also the deviations from the oracle; oracle-side flip statistics on "
-                                  "blobs: tests/test_gpu_streamlined.py (bench.py may use oracle/ only in cpu_baseline)",
+                                  "(tests/test_gpu_baseline_configs.py::test_bench_headline_workload_matches_oracle); "
+                                  "oracle-side flip statistics at 10^6 bots and on blobs: tests/test_gpu_streamlined.py "
+                                  "(bench.py may use oracle/ only in cpu_baseline)",
                        "window_steps": 10, "max_abs_dpos": float(d.max()),
                        "median_abs_dpos": float(np.median(d)), "bots_beyond_1e-5_relative": int((rel > 1e-5).sum()),
                        "com_abs_dev": com},
             "note": "opt-in: pbSimSetForceVariant(sim, 3).  v_rsq/v_rcp/FMA arithmetic, |F_attr| taken from its "
                     "coefficient, contact terms added after attraction terms.  Not bit-identical; held to 1e-5 "
-                    "relative over 10-step windows by tests/test_gpu_streamlined.py.  `value` above is the exact "
-                    "kernel."}
+                    "relative over 10-step windows by tests/test_gpu_streamlined.py.  `value` of the line is the exact "
+                    "kernel."})
+    return out
 
 
-def both_sums_leg(pb, n, pitch, steps, warmup):
+def both_sums_leg(pb, n, pitch, steps, warmup, warm=None):
     """The same workload with BOTH magnitude sums maintained (pbSimSetForceSums mode 1: what a batch with
     constrained_contraction set runs), so the line shows what leaving out the dead Sum|F_attr| is worth.
     Positions, velocities, radii, phases and absForce_r are bit-identical in the two modes
     (tests/test_gpu_dead_sum.py)."""
     sim = make_sim(pb, n, pitch, seed=1)
     sim.set_force_sums(1)
-    sim.step(warmup)
-    done, ms = sim.step_timed(steps)
+    t = timed_leg(sim, warm, warmup, steps)
     cfg = sim.config()
     sim.close()
-    return {"value": n * done / (ms * 1e-3), "unit": "particle-steps/s (device time)", "steps": done,
-            "us_per_step": ms * 1e3 / max(done, 1), "attraction_sums": cfg["attraction_sums"],
-            "dead_sum_form": cfg["dead_sum_form"]}
+    out = leg_fields(t, n)
+    out.update({"attraction_sums": cfg["attraction_sums"], "dead_sum_form": cfg["dead_sum_form"]})
+    return out
 
 
 class DevicePrewarm:
@@ -245,11 +288,15 @@ class DevicePrewarm:
     def __init__(self, pb, n, pitch, min_ms):
         self.min_ms = min_ms
         self.scratch = make_sim(pb, n, pitch, seed=12345) if min_ms > 0 else None
+        if self.scratch is not None:
+            self.scratch.set_force_variant(2)
         self.info = {"ms": 0.0, "steps": 0}
+        self.runs = 0
 
     def run(self):
         if self.scratch is None:
             return self.info
+        self.runs += 1
         steps, ms = 0, 0.0
         while ms < self.min_ms and steps < 20000:
             d, m = self.scratch.step_timed(100)
@@ -329,59 +376,85 @@ def measure_clock(pb, sim, ms_per_step, span=0.15):
         return None, str(e)
 
 
-def large_arena_leg(pb, pitch, warmup, steps, n=8_000_000):
+def large_arena_leg(pb, pitch, warmup, steps, n=8_000_000, warm=None):
     """SURVEY 8(d) caveat 2: the same lattice at 8 x 10^6 bots (544 MB of state, beyond the 256 MiB
     Infinity Cache) to show the kernel's sensitivity to true HBM traffic."""
     sim = make_sim(pb, n, pitch, seed=1)
-    sim.step(warmup)
-    s0 = sim.stats()
-    done, ms = sim.step_timed(steps)
-    s1 = sim.stats()
+    t = timed_leg(sim, warm, warmup, steps)
     cx, cy = sim.centroid()
     cfg = sim.config()
     sim.close()
-    launches = (s1["fused_launches"] - s0["fused_launches"]) + (s1["plain_launches"] - s0["plain_launches"])
-    us = ms * 1e3 / max(launches, 1)
+    out = leg_fields(t, n)
+    us = out.get("us_per_step_long", out["us_per_step"])
     achieved = ALG_BYTES_PER_PARTICLE_STEP * n / (us * 1e-6) / 1e9
-    return {"bots": n, "steps": done, "warmup": warmup, "us_per_step": us, "us_per_step_per_1e6_bots": us / (n / 1e6),
-            "value": n * done / (ms * 1e-3), "unit": "particle-steps/s (device time)",
-            "state_bytes": 68 * n, "finite_at_end": bool(cx == cx and cy == cy),
-            "force_variant": cfg["force_variant"], "lanes_per_bot": cfg["lanes_per_bot"],
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS},
-            "note": "working set beyond the Infinity Cache: if HBM bound the step would cost > 8x the 10^6-bot one"}
+    out.update({"bots": n, "warmup": warmup, "us_per_step_per_1e6_bots": out["us_per_step"] / (n / 1e6),
+                "state_bytes": 68 * n, "finite_at_end": bool(cx == cx and cy == cy),
+                "force_variant": cfg["force_variant"], "lanes_per_bot": cfg["lanes_per_bot"],
+                "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS,
+                             "over": "us_per_step_long" if "us_per_step_long" in out else "us_per_step"},
+                "note": "working set beyond the Infinity Cache: if HBM bound the step would cost > 8x the 10^6-bot one"})
+    if "us_per_step_long" in out:
+        out["us_per_step_per_1e6_bots_long"] = out["us_per_step_long"] / (n / 1e6)
+    return out
 
 
-def blob_leg(pb, n, steps, warmup):
+class BlobPlacement:
+    """The 10^6-bot random blob of the `random_blob` leg, grown on a host thread from the moment bench.py starts
+    (4-14 s of one core, `pb_placement fastblob`) while the device legs before it run: host work that used to sit
+    between device legs and leave the GPU idle for seconds."""
+
+    def __init__(self, n):
+        import threading
+        self.n, self.pos, self.place_s, self.err = n, None, None, None
+        self._t = threading.Thread(target=self._work, daemon=True)
+        self._t.start()
+
+    def _work(self):
+        try:
+            from particlerobotsimulations_amd import host
+            t0 = time.perf_counter()
+            h = host.HostSim(os.path.join(ROOT, "examples", "million_bot_blob.cfg"), engine="host", nCells=str(self.n))
+            self.place_s = time.perf_counter() - t0
+            self.pos = h.get("pos")
+            h.close()
+        except Exception as e:  # reported by the leg
+            self.err = e
+
+    def get(self):
+        self._t.join()
+        if self.err is not None:
+            raise self.err
+        return self.pos, self.place_s
+
+
+def blob_leg(pb, n, steps, warmup, placement, warm=None):
     """the same arena holding a RANDOM BLOB of n bots grown by the reference's placement
     rule with the O(N) generator (`pb_placement fastblob`, Particlebot::placeFastBlob) instead of the
     lattice: the reference's own kind of initial state at a size its O(N^1.5) loop cannot reach."""
     import numpy as np
-    from particlerobotsimulations_amd import host
-    t0 = time.perf_counter()
-    h = host.HostSim(os.path.join(ROOT, "examples", "million_bot_blob.cfg"), engine="host", nCells=str(n))
-    place_s = time.perf_counter() - t0
-    pos = h.get("pos")
-    h.close()
+    pos, place_s = placement.get()
     sp, keep = workload_params(n, seed=1)
     sim = pb.Sim(sp, wall_half=240.0, keepalive=keep)
     sim.set_force_variant(2)
     sim.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
                   phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
-    sim.step(warmup)
-    done, ms = sim.step_timed(steps)
+    t = timed_leg(sim, warm, warmup, steps)
     st = sim.get_state()
     cx, cy = sim.centroid()
     sim.close()
-    us = ms * 1e3 / max(done, 1)
+    out = leg_fields(t, n)
+    us = out.get("us_per_step_long", out["us_per_step"])
     achieved = ALG_BYTES_PER_PARTICLE_STEP * n / (us * 1e-6) / 1e9
-    return {"bots": n, "placement": "pb_placement fastblob (examples/million_bot_blob.cfg)", "placement_s": place_s,
-            "steps": done, "warmup": warmup, "us_per_step": us, "value": n * done / (ms * 1e-3),
-            "unit": "particle-steps/s (device time)", "finite_at_end": bool(cx == cx and cy == cy),
-            "bots_in_contact_frac": float((st["absForce_r"] > 0).mean()),
-            "max_speed": float(np.abs(st["vel"]).max()),
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS}}
+    out.update({"bots": n, "placement": "pb_placement fastblob (examples/million_bot_blob.cfg), on a host thread "
+                                        "beside the legs before this one", "placement_s": place_s,
+                "warmup": warmup, "finite_at_end": bool(cx == cx and cy == cy),
+                "bots_in_contact_frac": float((st["absForce_r"] > 0).mean()),
+                "max_speed": float(np.abs(st["vel"]).max()),
+                "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS,
+                             "over": "us_per_step_long" if "us_per_step_long" in out else "us_per_step"}})
+    return out
 
 
 # ---- ensemble workloads (BASELINE configs[3] and configs[4]) -------------------------------------
@@ -394,14 +467,21 @@ ENSEMBLE_WORKLOADS = {
 }
 
 
-def ensemble_batches(workload, rank, world, members_per_gpu):
+FULL_RUN = {   # the BASELINE configuration at full length (SURVEY 8(d)): max_time, timesteps per member, sub-batch
+    "ensemble4": {"max_time": "1200", "steps": 120000, "sub_batch": 0},    # 100 actuation cycles; members of 500 / 201 bots
+    "ensemble5": {"max_time": "120", "steps": 12000, "sub_batch": 8},      # 10 cycles; 10^5-bot members, placement 1.4 s each
+}
+
+
+def ensemble_batches(workload, rank, world, members_per_gpu, members_total=None, max_time="1e9"):
     """[(cfg_path, common, [override text per local member], [global member ids])] for this rank.
-    Global member k -> rank k mod world (ensemble.shard), so N GPUs run N x members_per_gpu members."""
+    Global member k -> rank k mod world (ensemble.shard).  Weak form: N GPUs run N x members_per_gpu members per
+    .cfg; strong form (members_total): a FIXED number of members per .cfg, whatever N is."""
     from particlerobotsimulations_amd import ensemble
-    total = members_per_gpu * world
+    total = members_total if members_total is not None else members_per_gpu * world
     ids = ensemble.shard(total, rank, world)
     ex = lambda name: os.path.join(ROOT, "examples", name)
-    big = {"max_time": "1e9", "dump_interval": "6"}
+    big = {"max_time": max_time, "dump_interval": "6"}
     if workload == "ensemble4":
         return [(ex("example_obstacle.cfg"), big, [f"seed\n{1000 + k}" for k in ids], ids),
                 (ex("example_object_transport.cfg"), big, [f"seed\n{1000 + k}" for k in ids], ids)]
@@ -413,16 +493,82 @@ def ensemble_batches(workload, rank, world, members_per_gpu):
     return [(ex("example_dead_cells.cfg"), common, over, ids)]
 
 
-def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, rank, world, dist, torch):
+def ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu=None, members_total=None, max_steps=None,
+                        host_threads=0):
+    """One ensemble run END TO END, as a user of bin/particlebot_ensemble experiences it: from the moment the
+    members exist only as override strings to the moment rank 0 holds every member's summary rows -- host placement
+    (overlapped with device stepping by the sub-batch pipeline, pbEnsemblePipeline*), state upload, every timestep
+    of the configuration at FULL LENGTH (FULL_RUN; max_steps bounds it for quick tests), the dead-bot draws, the
+    summary reductions and the one RCCL gather.  Wall clock between two barriers, max over ranks.
+    Collective: every rank calls it.  Returns the result on rank 0, None elsewhere."""
+    import threading
+
+    import numpy as np
+    from particlerobotsimulations_amd import ensemble
+    full = FULL_RUN[workload]
+    batches = ensemble_batches(workload, rank, world, members_per_gpu, members_total, max_time=full["max_time"])
+    steps_cap = full["steps"] + 1 if max_steps is None else int(max_steps)
+
+    def barrier():
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+    barrier()
+    t0 = time.perf_counter()
+    pipes = [ensemble.PipelinedEnsemble(cfg, over, common, sub_batch=full["sub_batch"], host_threads=host_threads)
+             for cfg, common, over, _ in batches]   # placement starts here, on the producer threads
+    done = [0] * len(pipes)
+
+    def one(i):
+        done[i] = pipes[i].run(steps_cap)
+    th = [threading.Thread(target=one, args=(i,)) for i in range(1, len(pipes))]
+    for t in th:
+        t.start()
+    one(0)
+    for t in th:
+        t.join()
+    total_members = members_total if members_total is not None else members_per_gpu * world
+    gathered = [ensemble.gather_summaries(p.rows, total_members, rank, world, dist,
+                                          "cuda" if dist is not None else "cpu") for p in pipes]
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    timings = [p.timings for p in pipes]
+    bots = [getattr(p, "n", 0) for p in pipes]
+    for p in pipes:
+        p.close()
+    if rank != 0:
+        return None
+    steps = done[0]
+    work = sum(b * total_members * d for b, d in zip(bots, done))
+    assert all(np.isfinite(g[:, -1]).all() for g in gathered), "an ensemble member went NaN"
+    return {"value_end_to_end": work / wall, "unit": "particle-steps/s (wall: placement + upload + steps + gather)",
+            "wall_s": wall, "steps_per_member": steps, "members_total": total_members * len(pipes),
+            "bots_per_member": bots, "sims_per_s_end_to_end": total_members * len(pipes) / wall,
+            "scaling": "strong" if members_total is not None else "weak", "n_gpus": world,
+            "rows_gathered": [list(g.shape) for g in gathered],
+            "pipeline_rank0": timings,
+            "host_share_rank0": [tm["placement_wait_s"] / max(tm["wall_s"], 1e-9) for tm in timings],
+            "note": "placement_wait_s is the time the device-driving thread waited for the host (the unhidden part of "
+                    "placement); placement_cpu_s is what the host spent in all; FULL configuration length unless "
+                    "steps_per_member says otherwise"}
+
+
+def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, rank, world, dist, torch,
+                     members_total=None, end_to_end=True, e2e_steps=None, strong_total=None):
     """K timesteps of an ensemble workload on every rank (member k on rank k mod N), then the path's one
-    exchange (the summary rows, over RCCL when there is a process group).  Collective: every rank calls
+    exchange (the summary rows, over RCCL when there is a process group); then (end_to_end) the same ensemble run
+    end to end at full length through the placement/stepping pipeline.  Collective: every rank calls
     it.  Returns (result dict on rank 0 else None, this rank's batches)."""
     import threading
 
     import numpy as np
     from particlerobotsimulations_amd import ensemble
     warm = DevicePrewarm(pb, 250_000, LATTICE_PITCH, prewarm_ms)
-    batches = ensemble_batches(workload, rank, world, members_per_gpu)
+    batches = ensemble_batches(workload, rank, world, members_per_gpu, members_total)
     t_place = time.perf_counter()
     ens = [ensemble.LocalEnsemble(cfg, over, common) for cfg, common, over, _ in batches]
     t_place = time.perf_counter() - t_place
@@ -449,44 +595,60 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
             torch.cuda.synchronize()
             dist.barrier()
 
+    def timed(nsteps):
+        barrier()
+        t0 = time.perf_counter()
+        done = drive(nsteps)
+        barrier()
+        wall = time.perf_counter() - t0
+        assert all(d == nsteps for d in done), (done, nsteps)
+        if dist is not None:
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall
+
     prewarm = warm.run()
     drive(warmup)
-    barrier()
-    t0 = time.perf_counter()
-    done = drive(steps)
-    barrier()
-    wall = time.perf_counter() - t0
+    wall = timed(steps)
+    # a timed region under 50 ms is followed by one of >= 100 ms (every rank takes the same decision: the wall
+    # time is already the max over ranks)
+    wall_long, steps_long = None, None
+    if wall < SHORT_MS * 1e-3:
+        steps_long = min(int(LONG_MS * 1e-3 / (wall / steps)) + 1, 200000)
+        wall_long = timed(steps_long)
     warm.done()
-    assert all(d == steps for d in done), (done, steps)
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
     # the path's only exchange: every member's summary rows, gathered once over RCCL
-    total_members = members_per_gpu * world
+    total_members = members_total if members_total is not None else members_per_gpu * world
     gathered = [ensemble.gather_summaries(e.rows, total_members, rank, world, dist,
                                           "cuda" if dist is not None else "cpu") for e in ens]
     bots = [e.n for e in ens]
+    mine = [e.m for e in ens]
     for e in ens:
         e.close()
+    e2e = strong = None
+    if end_to_end:
+        e2e = ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu, members_total, e2e_steps)
+        if strong_total is not None and members_total is None:
+            strong = ensemble_end_to_end(workload, rank, world, dist, torch, None, strong_total, e2e_steps)
     if rank != 0:
         return None, batches
-    per_gpu_bots = sum(b * members_per_gpu for b in bots)
-    achieved = ALG_BYTES_PER_PARTICLE_STEP * per_gpu_bots * steps / wall / 1e9
+    all_bots = sum(b * total_members for b in bots)      # bots stepped per timestep over all ranks
+    achieved = ALG_BYTES_PER_PARTICLE_STEP * (all_bots / world) * steps / wall / 1e9
     last = [g[:, -1] for g in gathered]
     assert all(np.isfinite(l).all() for l in last), "an ensemble member went NaN"
-    return {
-        "value": world * per_gpu_bots * steps / wall, "unit": "particle-steps/s", "n_gpus": world, "steps": steps,
-        "warmup": warmup, "ms_per_step": wall * 1e3 / steps, "scaling": "weak",
+    out = {
+        "value": all_bots * steps / wall, "unit": "particle-steps/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": wall * 1e3 / steps, "scaling": "strong" if members_total is not None else "weak",
         "config": {"workload": f"{workload}: {ENSEMBLE_WORKLOADS[workload]}",
-                   "members_per_gpu": members_per_gpu * len(bots), "members_total": total_members * len(bots),
+                   "members_per_gpu": (members_per_gpu * len(bots)) if members_total is None else None,
+                   "members_total": total_members * len(bots),
                    "bots_per_member": bots, "dt": 0.01,
                    "parallelism": (f"member k -> rank k mod {world}; one batched pbSim per .cfg per GPU; "
                                    f"RCCL world size {dist.get_world_size()}" if dist is not None
                                    else "one GPU, no process group"),
                    "members_per_rank": [len(ensemble.shard(total_members, r, world)) * len(bots)
                                         for r in range(world)]},
-        "sims_per_s": world * members_per_gpu * len(bots) / wall,
         "placement_s": t_place, "device_prewarm": prewarm,
         "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -495,16 +657,28 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
                              "(host-driven schedule included); small members are latency-bound (DESIGN.md 6b)"},
         "summaries_last_row_time_comx_comy_dist": [[[float(x) for x in r] for r in l[:4]] for l in last],
         "summary_rows_gathered": [list(g.shape) for g in gathered],
-    }, batches
+    }
+    if wall_long is not None:
+        out.update(value_long=all_bots * steps_long / wall_long, steps_long=steps_long,
+                   ms_per_step_long=wall_long * 1e3 / steps_long)
+    if e2e is not None:
+        out["end_to_end"] = e2e
+        out["value_end_to_end"] = e2e["value_end_to_end"]
+        out["sims_per_s_end_to_end"] = e2e["sims_per_s_end_to_end"]
+    if strong is not None:
+        out["strong_end_to_end"] = strong
+    return out, batches
 
 
 def run_ensemble_workload(args, rank, world, dist, torch):
     import particlerobotsimulations_amd as pb
     res, batches = measure_ensemble(pb, args.workload, args.members_per_gpu, args.steps, args.warmup, args.prewarm_ms,
-                                    rank, world, dist, torch)
+                                    rank, world, dist, torch, members_total=args.members_total,
+                                    end_to_end=not args.no_end_to_end, e2e_steps=args.e2e_steps)
     if rank == 0:
         out = {"metric": "particle-steps/sec at 10^6 bots; achieved HBM GB/s vs peak; 1/2/4/8-GPU ensemble",
-               "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+               "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "host": host_info()}
         out.update(res)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_ensemble(batches, min(args.cpu_seconds, 10.0))
@@ -547,6 +721,20 @@ def cpu_baseline_ensemble(batches, budget_s):
             "sample": "; ".join(parts) + " (OpenMP over bots; reported, not optimised)"}
 
 
+def host_info():
+    """What the host-side arithmetic of the path runs on: the libm whose powf the phase update's minimum rests on
+    (tests/test_libm_pin.py checks its properties exhaustively) and the cores placement can use."""
+    import ctypes as C
+    from particlerobotsimulations_amd import host
+    L = host.lib()
+    L.pbHostLibcVersion.restype = C.c_char_p
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except Exception:
+        cpus = os.cpu_count()
+    return {"glibc": L.pbHostLibcVersion().decode(), "cpus": cpus}
+
+
 def emit(out):
     # the ONE JSON line goes last: push out whatever C libraries (RCCL's version banner) still hold
     # in stdio buffers first
@@ -586,6 +774,13 @@ def main():
                          "configs[3] / configs[4] as batched ensembles sharded member k -> rank k mod N")
     ap.add_argument("--members-per-gpu", type=int, default=None,
                     help="ensemble workloads: members per GPU and per .cfg (default 32 for ensemble4, 8 for ensemble5)")
+    ap.add_argument("--members-total", type=int, default=None,
+                    help="ensemble workloads: a FIXED number of members per .cfg over all GPUs (strong scaling: "
+                         "BASELINE configs[3] is 256, configs[4] 1024) instead of --members-per-gpu per GPU (weak)")
+    ap.add_argument("--e2e-steps", type=int, default=None,
+                    help="bound the timesteps per member of the ensemble end-to-end run (default: the configuration's "
+                         "full length, 120000 for ensemble4 and 12000 for ensemble5)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the ensemble end-to-end run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-survey-literal", action="store_true")
     ap.add_argument("--no-streamlined", action="store_true")
@@ -596,7 +791,7 @@ def main():
     ap.add_argument("--no-ensemble-leg", action="store_true")
     ap.add_argument("--prewarm-ms", type=float, default=100.0,
                     help="device time of scratch work before the measured simulation (clock ramp); 0 disables")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the cpu_baseline sample")
     ap.add_argument("--force-variant", type=int, default=2, choices=[0, 1, 2, 3],
                     help="force kernel of the arena workload (default 2, the exact kernel = the headline).  3 = the "
                          "opt-in streamlined kernel: for profiling it with tools/profile.sh; the line then says "
@@ -644,7 +839,10 @@ def main():
     global HEADLINE_VARIANT
     HEADLINE_VARIANT = args.force_variant
     n = args.bots
-    warm = DevicePrewarm(pb, n, args.pitch, args.prewarm_ms)
+    # host work for a later leg starts now, on its own thread, so that no device leg waits for it
+    blob = BlobPlacement(n) if (rank == 0 and world == 1 and not args.no_blob) else None
+    # one scratch arena for the whole run: stepped for >= prewarm_ms immediately before EVERY timed leg
+    warm = DevicePrewarm(pb, min(n, 1_000_000), args.pitch, args.prewarm_ms)
     sim = make_sim(pb, n, args.pitch, seed=1 + rank)
     cfg = sim.config()
     assert cfg["force_variant"] == args.force_variant, cfg  # `value` is the exact kernel unless --force-variant says otherwise
@@ -663,9 +861,13 @@ def main():
     done, dev_ms = sim.step_timed(args.steps)
     barrier()
     wall = time.perf_counter() - t0
-    warm.done()
     s1 = sim.stats()
     assert done == args.steps, (done, args.steps)
+    # a timed region under 50 ms of device time (the driver's --steps 20 is ~2 ms) is followed at once by one of
+    # >= 100 ms, reported beside `value` as value_long (per rank, no collective inside)
+    long_steps, long_ms = 0, 0.0
+    if dev_ms < SHORT_MS:
+        long_steps, long_ms = sim.step_timed(min(int(LONG_MS / max(dev_ms / done, 1e-6)) + 1, 400000))
 
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
@@ -682,14 +884,17 @@ def main():
         summaries = [[sim.time, cx, cy]]
     assert cx == cx and cy == cy, "simulation state went NaN: the benchmark workload is invalid"
 
-    # BASELINE's "1/2/4/8-GPU ensemble": configs[3] (obstacle + object-transport seed ensembles, 32 members of
-    # each per GPU, member k on rank k mod N, RCCL gather of the summary rows) measured beside the arena at
-    # every N, without touching `value`.  Collective: every rank runs it.
+    # BASELINE's "1/2/4/8-GPU ensemble": configs[3] (obstacle + object-transport seed ensembles) measured beside the
+    # arena at every N, without touching `value`: (a) weak form, 32 + 32 members per GPU: K timesteps in steady state
+    # (`value`) and the whole 120 000-step run end to end through the placement/stepping pipeline
+    # (`value_end_to_end`); (b) strong form, configs[3] as written: 256 + 256 members in all, end to end.
+    # Member k on rank k mod N, RCCL gather of the summary rows.  Collective: every rank runs it.
     ens_leg = None
     if not args.no_ensemble_leg:
         sim.synchronize()
-        ens_leg, _ = measure_ensemble(pb, "ensemble4", 32, min(max(args.steps, 200), 4000), 20, 0.0, rank, world,
-                                      dist, torch)
+        ens_leg, _ = measure_ensemble(pb, "ensemble4", 32, min(max(args.steps, 200), 4000), 20, args.prewarm_ms, rank,
+                                      world, dist, torch, end_to_end=not args.no_end_to_end, e2e_steps=args.e2e_steps,
+                                      strong_total=256)
     if rank == 0:
         launches = (s1["fused_launches"] - s0["fused_launches"]) + (s1["plain_launches"] - s0["plain_launches"])
         value = world * n * args.steps / wall
@@ -727,7 +932,7 @@ def main():
                          "shader_clock_source": ("s_memtime / s_memrealtime of a sampler wave on its own stream beside "
                                                  f"{clock_span:.2f} s more of the same steps (after the timed region)"
                                                  if clock_mhz else None),
-                         "kernel": "k_force<FUSE> (forces of step n + radius/integration of step n+1)",
+                         "kernel": "k_force, fuse = 1 (forces of step n + radius/integration of step n+1)",
                          "launches": launches, "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * n,
                          "note": "achieved/peak/frac are the HBM accounting SURVEY 8(d) prescribes (64 algorithmic "
@@ -740,27 +945,46 @@ def main():
             "device_ms_timed_region": dev_ms,
             "device_prewarm": prewarm,
             "summaries_time_comx_comy": summaries,
+            "host": host_info(),
         }
+        out["roofline"]["alg_bytes_note"] = (
+            "64 B per particle-step = read pos 8 + vel 8 + rad 4 + phase 4 + dead 4 + absForce_a 4 + absForce_r 4, write "
+            "pos 8 + vel 8 + rad 4 + absForce_a 4 + absForce_r 4 (SURVEY 8(d)); the headline form does not touch "
+            "absForce_a (no reader: constrained_contraction 0) but is still priced at 64; frac_both_sums prices the "
+            "form that maintains it (value_with_both_sums)")
+        if long_steps:
+            us_long = long_ms * 1e3 / long_steps
+            out["value_long"] = n * long_steps / (long_ms * 1e-3) * world
+            out["steps_long"] = long_steps
+            out["roofline"]["avg_launch_us_long"] = us_long
+            out["roofline"]["frac_long"] = ALG_BYTES_PER_PARTICLE_STEP * n / (us_long * 1e-6) / 1e9 / HBM_PEAK_GBS
+            out["value_long_note"] = (f"the {args.steps} timed steps were {dev_ms:.2f} ms of device time: the same "
+                                      f"simulation stepped {long_steps} more steps right behind them (device time, "
+                                      "rank 0's arena x n_gpus)")
         if ens_leg is not None:
             out["ensemble_leg"] = ens_leg
         sim.close()
         if world == 1 and not args.no_large_arena:
-            out["large_arena"] = large_arena_leg(pb, args.pitch, 20, min(args.steps, 200))
-        if world == 1 and not args.no_blob:
-            out["random_blob"] = blob_leg(pb, n, min(args.steps, 600), args.warmup)
-        if world == 1 and not args.no_survey_literal:
-            out["survey_literal_lattice"] = survey_literal(pb, n, args.steps, args.warmup)
+            out["large_arena"] = large_arena_leg(pb, args.pitch, 20, min(args.steps, 200), warm=warm)
         if world == 1 and not args.no_both_sums:
-            out["both_sums"] = both_sums_leg(pb, n, args.pitch, min(args.steps, 400), max(args.warmup, 100))
+            out["both_sums"] = both_sums_leg(pb, n, args.pitch, min(args.steps, 400), max(args.warmup, 100), warm=warm)
             # top-level, next to `value`: the same workload with the dead Sum|F_attr| computed all the same
             out["value_with_both_sums"] = out["both_sums"]["value"]
+            us_b = out["both_sums"].get("us_per_step_long", out["both_sums"]["us_per_step"])
+            out["roofline"]["frac_both_sums"] = ALG_BYTES_PER_PARTICLE_STEP * n / (us_b * 1e-6) / 1e9 / HBM_PEAK_GBS
         if world == 1 and not args.no_streamlined:
-            out["streamlined"] = streamlined_leg(pb, n, args.pitch, args.steps, args.warmup)
+            out["streamlined"] = streamlined_leg(pb, n, args.pitch, args.steps, args.warmup, warm=warm)
+        if world == 1 and not args.no_blob:
+            out["random_blob"] = blob_leg(pb, n, min(args.steps, 600), args.warmup, blob, warm=warm)
+        if world == 1 and not args.no_survey_literal:
+            out["survey_literal_lattice"] = survey_literal(pb, n, args.steps, args.warmup)
+        warm.done()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.pitch, args.cpu_seconds)
         emit(out)
     else:
         sim.close()
+        warm.done()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

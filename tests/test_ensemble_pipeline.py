@@ -32,10 +32,10 @@ def test_members_do_not_depend_on_split_or_threads():
         assert np.array_equal(sums, ref), (sub, threads)
 
 
-def test_members_equal_the_one_batch_form(orc):
-    """The same members through the oracle's placement + dead draw: the pipeline's members are the reference's."""
+def test_members_are_the_oracles(orc):
+    """The same members through the oracle's placement + dead draw (the draw is due at time 0, so the pipeline draws
+    it with the placement; the oracle draws it at the top of its first step)."""
     sums, _ = _dry(3, 2, m=5)
-    import hashlib  # noqa: F401  (FNV below, as the C side)
 
     def fnv(*arrays):
         h = 1469598103934665603
@@ -45,16 +45,13 @@ def test_members_equal_the_one_batch_form(orc):
         return h
     for k in range(5):
         P = orc.load_cfg(CFG, nCells=400, seed=1000 + k, nDead=5 + k)
-        o = orc.Sim(P, reset=True)
-        o.run(0) if hasattr(o, "run") else None
-        dead = o.get("dead").copy()
-        if not dead.any():          # the oracle draws at the top of its first step; placement state otherwise equal
-            o2 = orc.Sim(P, reset=True)
-            o2.run(1)
-            dead = o2.get("dead")
-            o2.close()
-        assert int(sums[k]) == fnv(o.get("pos"), o.get("rad"), dead.astype(np.int32)), k
-        o.close()
+        placed = orc.Sim(P, reset=True)
+        pos, rad = placed.get("pos"), placed.get("rad")
+        placed.run(1)
+        dead = placed.get("dead").astype(np.int32)
+        assert dead.sum() == 5 + k
+        assert int(sums[k]) == fnv(pos, rad, dead), k
+        placed.close()
 
 
 def test_look_ahead_is_bounded():

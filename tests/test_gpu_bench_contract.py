@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_json_line_with_the_contract_keys():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bots", "200000", "--steps", "60",
-                          "--warmup", "20", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900,
-                         cwd=ROOT)
+                          "--warmup", "20", "--cpu-seconds", "1", "--e2e-steps", "1500"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     d = json.loads(lines[-1])  # the JSON line is the last line of stdout
@@ -33,8 +33,22 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     el = d["ensemble_leg"]   # BASELINE configs[3] measured beside the arena (what a SCALE run sees at every N)
     assert el["config"]["bots_per_member"] == [500, 201] and el["config"]["members_per_gpu"] == 64 and el["value"] > 1e8
     assert el["summary_rows_gathered"][0][0] == 32
+    assert el["device_prewarm"]["ms"] >= 100.0                       # every leg is pre-warmed, not only the headline
+    # the ensemble END TO END (placement + upload + steps + gather, through the sub-batch pipeline), weak and strong
+    e2e, strong = el["end_to_end"], el["strong_end_to_end"]
+    assert e2e["scaling"] == "weak" and e2e["members_total"] == 64 and e2e["steps_per_member"] == 1500
+    assert strong["scaling"] == "strong" and strong["members_total"] == 512 and strong["rows_gathered"][0][0] == 256
+    assert 0 < e2e["value_end_to_end"] and el["value_end_to_end"] == e2e["value_end_to_end"]
+    assert e2e["pipeline_rank0"][0]["sub_batches"] == 1 and "sims_per_s" not in el
+    # short timed regions carry a second, >= 100 ms figure
+    assert d["device_ms_timed_region"] < 50.0 and d["value_long"] > 0 and d["roofline"]["frac_long"] > 0
+    assert d["steps_long"] * d["roofline"]["avg_launch_us_long"] * 1e-3 >= 99.0
+    assert "glibc" in d["host"] and d["host"]["cpus"] >= 1
+    assert "frac_both_sums" in d["roofline"] and "alg_bytes_note" in d["roofline"]
+    assert 0 < d["roofline"]["frac_both_sums"] <= d["roofline"]["frac_long"] * 1.05
     la = d["large_arena"]
-    assert la["bots"] == 8_000_000 and la["finite_at_end"] and la["us_per_step"] > 0
+    assert la["bots"] == 8_000_000 and la["finite_at_end"] and la["us_per_step"] > 0 and la["us_per_step_long"] > 0
+    assert la["device_prewarm_ms"] >= 100.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert abs(d["value"] - 200000 * 60 / (d["ms_per_step"] * 60 * 1e-3)) / d["value"] < 1e-6
     c = d["cpu_baseline"]
@@ -45,7 +59,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # absForce_a has no reader and is not computed); the same workload with both sums kept is reported beside it
     assert d["config"]["attraction_sums"] == 0 and d["config"]["dead_sum_form"] == 1
     b = d["both_sums"]
-    assert b["attraction_sums"] == 1 and b["dead_sum_form"] == 0 and 0 < b["value"] < d["value"] * 1.05
+    assert b["attraction_sums"] == 1 and b["dead_sum_form"] == 0 and 0 < b["value_long"] < d["value_long"] * 1.05
+    assert d["random_blob"]["device_prewarm_ms"] >= 100.0 and d["random_blob"]["value"] > 0
 
 
 def _bench(*args):
@@ -61,18 +76,19 @@ def test_ensemble_workload_line_and_rccl_path_on_one_gpu():
     runs the max-over-ranks all_reduce and the all_gather of the summary rows, and must report the
     SAME summaries."""
     common = ("--workload", "ensemble4", "--members-per-gpu", "6", "--steps", "700", "--warmup", "50",
-              "--cpu-seconds", "1")
+              "--cpu-seconds", "1", "--e2e-steps", "900")
     a = _bench(*common)
     b = _bench(*common, "--force-dist", "--no-cpu-baseline")
     for d in (a, b):
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                  "vs_baseline", "dtype", "data", "config", "roofline", "sims_per_s"):
+                  "vs_baseline", "dtype", "data", "config", "roofline", "value_end_to_end", "sims_per_s_end_to_end"):
             assert k in d, k
         assert d["n_gpus"] == 1 and d["steps"] == 700 and d["scaling"] == "weak" and d["unit"] == "particle-steps/s"
         assert d["config"]["members_per_gpu"] == 12 and d["config"]["bots_per_member"] == [500, 201]
         assert d["config"]["members_per_rank"] == [12]
         assert abs(d["value"] - 6 * (500 + 201) * 700 / (d["ms_per_step"] * 700 * 1e-3)) / d["value"] < 1e-6
         assert d["summary_rows_gathered"] == [[6, 3, 4], [6, 3, 4]]   # rows at t = 0, 0.01 and 6.0
+        assert d["end_to_end"]["steps_per_member"] == 900 and d["end_to_end"]["rows_gathered"] == [[6, 3, 4], [6, 3, 4]]
     assert "RCCL world size 1" in b["config"]["parallelism"]
     assert a["summaries_last_row_time_comx_comy_dist"] == b["summaries_last_row_time_comx_comy_dist"]
     assert a["cpu_baseline"]["kind"] == "port" and a["cpu_baseline"]["value"] > 0
@@ -81,9 +97,18 @@ def test_ensemble_workload_line_and_rccl_path_on_one_gpu():
 def test_ensemble5_workload_line():
     """BASELINE configs[4] at bench scale: 10^5-bot members of the dead-fraction sweep as one batch."""
     d = _bench("--workload", "ensemble5", "--members-per-gpu", "2", "--steps", "60", "--warmup", "10",
-               "--no-cpu-baseline")
+               "--no-cpu-baseline", "--e2e-steps", "80")
     assert d["config"]["bots_per_member"] == [100000] and d["config"]["members_per_gpu"] == 2
     assert d["value"] > 1e8 and d["summary_rows_gathered"] == [[2, 2, 4]]
+    assert d["end_to_end"]["steps_per_member"] == 80 and d["end_to_end"]["pipeline_rank0"][0]["placement_cpu_s"] > 0.5
+
+
+def test_ensemble_strong_form_members_total():
+    """--members-total: a fixed number of members over all GPUs (BASELINE configs[3] is 256 + 256)."""
+    d = _bench("--workload", "ensemble4", "--members-total", "10", "--steps", "300", "--warmup", "20",
+               "--no-cpu-baseline", "--e2e-steps", "400")
+    assert d["scaling"] == "strong" and d["config"]["members_total"] == 20 and d["config"]["members_per_rank"] == [20]
+    assert d["end_to_end"]["scaling"] == "strong" and d["end_to_end"]["members_total"] == 20
 
 
 def test_arena_line_through_rccl_with_one_rank_and_gpus_flag_is_checked():
@@ -91,7 +116,7 @@ def test_arena_line_through_rccl_with_one_rank_and_gpus_flag_is_checked():
     runs the barrier / max-over-ranks all_reduce / all_gather of the arena summaries.  And `--gpus 2`
     without a launcher on a one-GPU box refuses loudly instead of silently running one arena."""
     d = _bench("--bots", "150000", "--steps", "40", "--warmup", "10", "--force-dist", "--no-cpu-baseline",
-               "--no-survey-literal", "--no-streamlined", "--no-large-arena", "--no-blob")
+               "--no-survey-literal", "--no-streamlined", "--no-large-arena", "--no-blob", "--e2e-steps", "300")
     assert d["n_gpus"] == 1 and len(d["summaries_time_comx_comy"]) == 1 and d["value"] > 0
     assert "RCCL world size 1" in d["ensemble_leg"]["config"]["parallelism"]   # the leg's gather went over RCCL
     import torch

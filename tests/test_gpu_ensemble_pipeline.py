@@ -1,0 +1,81 @@
+"""GPU parity of the PIPELINED ensemble (pbEnsemblePipeline*, csrc/pb_capi.cpp): host
+placement of sub-batch k+1 overlapped with device stepping of sub-batch k.  The summary rows and the final states
+must not depend on the sub-batch size or on the number of producer threads, and every member must equal its own
+stand-alone CPU-oracle run (rows within the centroid's double-vs-float64-mean rounding, states bit for bit).
+Reference behaviour per member: main.cpp:354-361 (dump; update) on Particlebot::update (particlebot.cpp:170-300)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_bit_equal
+from test_gpu_baseline_configs import EX, oracle_member
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg,over", [("example_obstacle.cfg", {}),
+                                      ("example_dead_cells.cfg", {"nCells": "700", "nDead": "150"})])
+def test_rows_and_states_do_not_depend_on_the_split(orc, cfg, over):
+    from particlerobotsimulations_amd import ensemble
+    seeds = [1000 + k for k in range(16)]
+    common = dict({"max_time": "12.6", "dump_interval": "6"}, **over)
+    members = [f"seed\n{s}" for s in seeds]
+    ref_rows, ref_steps, ref_states = ensemble.run_local(EX(cfg), members, common, final_state=True)
+    assert ref_rows.shape[:2] == (16, 4) and ref_steps in (1260, 1261)
+    for sub, threads in ((8, 3), (5, 1), (32, 4), (0, 2)):   # even split, ragged split, one batch (two spellings)
+        p = ensemble.PipelinedEnsemble(EX(cfg), members, common, sub_batch=sub, host_threads=threads,
+                                       keep_final_states=True)
+        steps = p.run()
+        tm = p.timings
+        assert steps == ref_steps
+        assert tm["sub_batches"] == (-(-16 // sub) if 0 < sub < 16 else 1) and tm["host_threads"] == threads
+        assert tm["wall_s"] > 0 and tm["device_s"] > 0 and tm["placement_cpu_s"] > 0
+        rows, states = p.rows, p.final_states()
+        p.close()
+        assert np.array_equal(rows.view(np.uint32), ref_rows.view(np.uint32)), (sub, threads)
+        for k in range(16):
+            for key in ("pos", "vel", "rad"):
+                assert_bit_equal(states[k][key], ref_states[k][key], f"{cfg} sub {sub} member {k}: {key}")
+    # ... and the members are the oracle's
+    for k in (0, 7, 15):
+        kv = dict(seed=seeds[k], max_time=12.6, dump_interval=6.0)
+        kv.update({a: int(b) for a, b in over.items()})
+        orows, osim = oracle_member(orc, EX(cfg), kv, 6.0)
+        assert np.array_equal(orows[:, 0].astype(np.float32), ref_rows[k, :, 0])
+        assert np.abs(orows[:, 1:] - ref_rows[k, :, 1:]).max() < 2e-6
+        for key in ("pos", "vel", "rad"):
+            assert_bit_equal(ref_states[k][key], osim.get(key), f"{cfg} member {k} vs oracle: {key}")
+        osim.close()
+
+
+def test_max_steps_bounds_every_sub_batch_alike(orc):
+    from particlerobotsimulations_amd import ensemble
+    members = [f"seed\n{2000 + k}" for k in range(6)]
+    common = {"max_time": "1e9", "dump_interval": "6"}
+    a = ensemble.PipelinedEnsemble(EX("example.cfg"), members, common, sub_batch=4, host_threads=2)
+    b = ensemble.PipelinedEnsemble(EX("example.cfg"), members, common, sub_batch=0, host_threads=2)
+    assert a.run(777) == 777 and b.run(777) == 777
+    assert np.array_equal(a.rows.view(np.uint32), b.rows.view(np.uint32)) and a.rows.shape[1] == 3  # t = 0, 0.01, 6
+    a.close(), b.close()
+
+
+def test_placement_is_hidden_behind_stepping():
+    """The point of the pipeline: with the host slower than it needs to be (ONE producer thread, the reference's
+    O(N^1.5) placement of 20 000-bot members) the wall time is close to max(host, device) + one sub-batch's placement,
+    not their sum."""
+    from particlerobotsimulations_amd import ensemble
+    members = [f"seed\n{3000 + k}\nnDead\n{400 * k}" for k in range(12)]
+    common = {"nCells": "20000", "light_x": "-20", "light_y": "0", "max_time": "30", "dump_interval": "6"}
+    cfg = EX("example_dead_cells.cfg")
+    p = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=2, host_threads=1)
+    steps = p.run()
+    tm = p.timings
+    p.close()
+    assert steps in (3000, 3001)
+    serial = tm["placement_cpu_s"] + tm["upload_s"] + tm["device_s"]
+    one_sub = tm["placement_cpu_s"] / 6
+    hidden = max(tm["placement_cpu_s"], tm["upload_s"] + tm["device_s"]) + one_sub
+    print("pipeline timings", tm, "serial would be", serial)
+    assert tm["wall_s"] < 1.25 * hidden + 0.3, (tm, hidden, serial)
+    assert tm["wall_s"] < 0.9 * serial or min(tm["placement_cpu_s"], tm["device_s"]) < 0.15 * serial, (tm, serial)
