@@ -550,6 +550,7 @@ def ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu=None
             "bots_per_member": bots, "sims_per_s_end_to_end": total_members * len(pipes) / wall,
             "scaling": "strong" if members_total is not None else "weak", "n_gpus": world,
             "rows_gathered": [list(g.shape) for g in gathered],
+            "last_rows_time_comx_comy_dist": [[[float(x) for x in r] for r in g[:4, -1]] for g in gathered],
             "pipeline_rank0": timings,
             "host_share_rank0": [tm["placement_wait_s"] / max(tm["wall_s"], 1e-9) for tm in timings],
             "note": "placement_wait_s is the time the device-driving thread waited for the host (the unhidden part of "

@@ -1,6 +1,5 @@
 set -x
 cd $GRAFT_REPO_ROOT
-nproc; free -g | head -2
-python -m pytest tests -m gpu -x -q 2>&1 | tail -15
-python bench.py --steps 400 --warmup 100 > gpurun_out/r3_bench_a.json 2> gpurun_out/r3_bench_a.err; tail -c 600 gpurun_out/r3_bench_a.err
-PB_PROFILE_LARGE=0 PB_PROFILE_VARIANT=3 bash tools/profile.sh r3_stream0 > gpurun_out/r3_stream0.log 2>&1; tail -30 gpurun_out/r3_stream0.log
+python -m pytest tests/test_gpu_ensemble_pipeline.py tests/test_gpu_bench_contract.py -m gpu -x -q -s 2>&1 | grep -v "^[0-9-]*\.[0-9]* [0-9-]*\.[0-9]* [0-9-]*\.[0-9]* $" | tail -30
+(time python bench.py --steps 20 --warmup 5) > gpurun_out/r3_bench_b20.json 2> gpurun_out/r3_bench_b20.err; tail -c 400 gpurun_out/r3_bench_b20.err
+(time python bench.py) > gpurun_out/r3_bench_b.json 2> gpurun_out/r3_bench_b.err; tail -c 400 gpurun_out/r3_bench_b.err
