@@ -1063,7 +1063,7 @@ int pbSimGetConfig(pbSim *S, pbSimConfig *cfg) {
   cfg->rng = S->rng;
   cfg->offsets64 = (!p.stream && p.big) ? 1 : 0;
   cfg->attraction_sums = attractionSumsKept(S) ? 1 : 0;
-  cfg->dead_sum_form = (cfg->resident ? !attractionSumsKept(S) : (!p.stream && !p.asum)) ? 1 : 0;
+  cfg->dead_sum_form = ((cfg->resident || p.stream) ? !attractionSumsKept(S) : !p.asum) ? 1 : 0;
   return PB_OK;
 }
 

@@ -30,6 +30,9 @@
 // (64 VGPRs, 28 spilled), 120.8 at 7 (72), 119.8 at 6 (80), 121.4 at 5 (81, no bound) against 114.0
 // for NB = 1 (63 VGPRs, 8 waves/SIMD): waves, not ILP inside a wave, are what fills the VALU pipe.
 
+#ifndef PB_SWEEP_EXPERIMENT
+#define PB_SWEEP_EXPERIMENT 0
+#endif
 #ifndef PB_TL_STAMP
 #define PB_TL_STAMP(word) do { } while (0)  // (pb_force.hip defines it in the -DPB_TIMELINE diagnostic build)
 #endif
@@ -282,12 +285,31 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
     if (!ASUM) rep.init(repCol);
     // (64-bit address arithmetic with a constant displacement: the displacement becomes the load's
     //  immediate offset, so the look-ahead loads need no address instructions of their own)
+#if PB_SWEEP_EXPERIMENT >= 2
+    // timing experiment (wrong results): no neighbour posrad loads at all
+    auto atI = [&](OffT off, int imm) __attribute__((always_inline)) {
+      float4 q = me;
+      asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z) : "v"(off));
+      q.x += 0.3f;
+      return q;
+    };
+#else
     auto atI = [&](OffT off, int imm) __attribute__((always_inline)) {
       return *(const float4 *)(prBytes + (uint64_t)off + imm);
     };
+#endif
+#if PB_SWEEP_EXPERIMENT >= 1
+    // timing experiment (wrong results): no neighbour velocity loads
+    auto vatI = [&](OffT hoff, int imm) __attribute__((always_inline)) {
+      float2 w = v;
+      asm volatile("" : "+v"(w.x), "+v"(w.y) : "v"(hoff));
+      return w;
+    };
+#else
     auto vatI = [&](OffT hoff, int imm) __attribute__((always_inline)) {
       return *(const float2 *)(velBytes + (uint64_t)hoff + imm);
     };
+#endif
     const OffT selfOff16 = selfOff + 16u;
     auto one = [&](const float4 &q, const float2 &vq, bool isLive) __attribute__((always_inline)) {
       const bool live[1] = {isLive};

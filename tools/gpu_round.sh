@@ -1,5 +1,7 @@
-set -x
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_ensemble_pipeline.py tests/test_gpu_bench_contract.py -m gpu -x -q -s 2>&1 | grep -v "^[0-9-]*\.[0-9]* [0-9-]*\.[0-9]* [0-9-]*\.[0-9]* $" | tail -30
-(time python bench.py --steps 20 --warmup 5) > gpurun_out/r3_bench_b20.json 2> gpurun_out/r3_bench_b20.err; tail -c 400 gpurun_out/r3_bench_b20.err
-(time python bench.py) > gpurun_out/r3_bench_b.json 2> gpurun_out/r3_bench_b.err; tail -c 400 gpurun_out/r3_bench_b.err
+python -m pytest tests/test_gpu_streamlined.py -m gpu -x -q 2>&1 | grep -v "^[0-9-]*\.[0-9]* [0-9-]*\.[0-9]* [0-9-]*\.[0-9]* $" | tail -3
+for rep in 1 2; do
+for lib in lib lib_x1 lib_x2; do
+  echo "== $lib"
+  python tools/ab_bench.py --libdir particlerobotsimulations_amd/$lib --variants 2,3 --bots 1000000 --rounds 4 --steps 300 --skip 300 2>&1 | tail -2 | cut -c1-120
+done; done
