@@ -147,6 +147,11 @@ class Particlebot {
                      float lightRadius = 0.25f);
   /* HostOnly engines follow an external clock */
   void setHostTime(float t) { time = t; }
+  /* The private placement / dead-draw generator's state and the host mirrors of a HostOnly instance: what an
+   * ensemble checkpoint saves and restores for a member whose device state lives in a batched pbSim. */
+  void getHostRngState(int out[36]) const { rng.getState(out); }
+  void setHostRngState(const int in[36]) { rng.setState(in); }
+  void restoreHostMirrors(const float *pos, const float *vel, const float *rad, const float *phase, const int *dead);
 
  protected:
   void _initialize();

@@ -986,6 +986,16 @@ bool Particlebot::writeFramePPM(const char *path, int width, int height, float c
   return fclose(fp) == 0 && ok;
 }
 
+void Particlebot::restoreHostMirrors(const float *pos, const float *vel, const float *rad, const float *phase,
+                                     const int *dead) {
+  const size_t n = params.nCells;
+  if (pos) memcpy(hPos, pos, 8 * n);
+  if (vel) memcpy(hVel, vel, 8 * n);
+  if (rad) memcpy(hRad, rad, 4 * n);
+  if (phase) memcpy(hphase, phase, 4 * n);
+  if (dead) memcpy(hDead, dead, 4 * n);
+}
+
 bool Particlebot::saveCheckpoint(FILE *fp) {
   if (engineKind != Engine::Fused || !fp) return false;
   const uint n = params.nCells;

@@ -1,0 +1,97 @@
+"""Command-line resume and checkpoints.  The reference's main() has a resume
+branch (/root/reference main.cpp:940-957 -> particlebot.cpp:369-411) that restarts from the last CSV row; the
+runners here also write EXACT checkpoints while they run, and a run that is killed and resumed from its last
+checkpoint must equal the uninterrupted run bit for bit: the same CSV bytes, the same final state."""
+import os
+import signal
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUN = os.path.join(ROOT, "particlerobotsimulations_amd", "bin", "particlebot_run")
+ENS = os.path.join(ROOT, "particlerobotsimulations_amd", "bin", "particlebot_ensemble")
+EX = lambda name: os.path.join(ROOT, "examples", name)
+
+
+def run(args, **kw):
+    return subprocess.run(args, capture_output=True, text=True, timeout=600, **kw)
+
+
+def state_part(path):
+    """a checkpoint file without the runner's trailer (which holds the CSV length and step counters)"""
+    b = open(path, "rb").read()
+    return b[:-24]
+
+
+@pytest.mark.parametrize("cfg,over", [("example_obstacle.cfg", ["--set", "max_time", "30"]),
+                                      ("example_dead_cells.cfg", ["--set", "max_time", "25", "--set", "time_to_dead", "3",
+                                                                  "--set", "pb_rng", "curand"])])
+def test_run_killed_and_resumed_equals_the_uninterrupted_run(tmp_path, cfg, over):
+    base = [RUN, EX(cfg), "--quiet", "--set", "dump_interval", "1", "--set", "testing", "1"] + over
+    a_csv, b_csv = str(tmp_path / "a.csv"), str(tmp_path / "b.csv")
+    # A: uninterrupted (checkpointing all the same: taking checkpoints must not change anything)
+    r = run(base + ["--set", "csv_filename", a_csv, "--checkpoint", str(tmp_path / "a.ck"), "--checkpoint-steps", "333",
+                    "--final-checkpoint", str(tmp_path / "a.final")])
+    assert r.returncode == 0, r.stderr
+    # B: dies at step 1200 (a checkpoint every 333 steps: the last one is from step 999; rows up to t = 12 are in
+    # the CSV by then and must be cut back), then resumes
+    r = run(base + ["--set", "csv_filename", b_csv, "--checkpoint", str(tmp_path / "b.ck"), "--checkpoint-steps", "333",
+                    "--stop-after-steps", "1200"])
+    assert r.returncode == 9, (r.returncode, r.stderr)
+    assert os.path.getsize(b_csv) > 0 and os.path.exists(tmp_path / "b.ck")
+    r = run(base + ["--set", "csv_filename", b_csv, "--resume", str(tmp_path / "b.ck"), "--checkpoint",
+                    str(tmp_path / "b.ck"), "--checkpoint-steps", "333", "--final-checkpoint", str(tmp_path / "b.final")])
+    assert r.returncode == 0, r.stderr
+    assert open(a_csv, "rb").read() == open(b_csv, "rb").read()
+    assert state_part(tmp_path / "a.final") == state_part(tmp_path / "b.final")
+    assert len(open(a_csv).read().splitlines()) >= 25
+
+
+def test_run_really_killed_at_an_arbitrary_moment(tmp_path):
+    """SIGKILL whenever: the wall-clock checkpoint cadence, a CSV with rows past the last checkpoint."""
+    base = [RUN, EX("example_obstacle.cfg"), "--quiet", "--set", "nCells", "4000", "--set", "max_time", "400",
+            "--set", "dump_interval", "2", "--set", "testing", "0"]
+    a_csv, b_csv, ck = str(tmp_path / "a.csv"), str(tmp_path / "b.csv"), str(tmp_path / "b.ck")
+    r = run(base + ["--set", "csv_filename", a_csv, "--final-checkpoint", str(tmp_path / "a.final")])
+    assert r.returncode == 0, r.stderr
+    p = subprocess.Popen(base + ["--set", "csv_filename", b_csv, "--checkpoint", ck, "--checkpoint-every", "0.05"],
+                         stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    t0 = time.time()
+    while not os.path.exists(ck) and p.poll() is None and time.time() - t0 < 120:
+        time.sleep(0.005)
+    time.sleep(0.12)
+    killed = p.poll() is None
+    p.send_signal(signal.SIGKILL)
+    p.wait()
+    assert os.path.exists(ck)
+    r = run(base + ["--set", "csv_filename", b_csv, "--resume", ck, "--final-checkpoint", str(tmp_path / "b.final")])
+    assert r.returncode == 0, r.stderr
+    assert open(a_csv, "rb").read() == open(b_csv, "rb").read(), f"killed in mid-run: {killed}"
+    assert state_part(tmp_path / "a.final") == state_part(tmp_path / "b.final")
+
+
+def test_resume_from_the_csv_like_the_reference(tmp_path):
+    """main.cpp:940-957: `cont` reads the last complete row of the run's own CSV and appends to it."""
+    csv = str(tmp_path / "run.csv")
+    base = [RUN, EX("example.cfg"), "--quiet", "--set", "csv_filename", csv, "--set", "testing", "1", "--set",
+            "dump_interval", "0.5", "--set", "phase_std", "0"]
+    assert run(base + ["--set", "max_time", "2"]).returncode == 0
+    rows_before = open(csv).read().splitlines()
+    assert run(base + ["--set", "max_time", "4", "--resume", csv]).returncode == 0
+    rows = open(csv).read().splitlines()
+    assert rows[:len(rows_before)] == rows_before and len(rows) > len(rows_before)
+    def times(lines):   # (the dump writes header lines too; data rows start with the time)
+        out = []
+        for r in lines:
+            try:
+                out.append(float(r.split(",")[0]))
+            except ValueError:
+                pass
+        return out
+    t0, t1 = times(rows_before), times(rows[len(rows_before):])
+    # (the resumed run dumps the row it restarted from again, as the reference's loop would)
+    assert t1[0] == pytest.approx(t0[-1], abs=0.011) and t1[-1] >= 3.99 and t0[-1] <= 2.02
