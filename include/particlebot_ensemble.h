@@ -62,6 +62,16 @@ typedef struct pbEnsembleTimings {
 } pbEnsembleTimings;
 void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
                                int nmembers, int sub_batch, int host_threads, int keep_final_states);
+/* The same with CHECKPOINTS under checkpoint_dir (created if missing): whenever a summary row is written, and
+ * when a sub-batch ends, every member of the sub-batch on the device is saved exactly (state arrays, stale slot
+ * layout, both generators, its rows so far; csrc/pb_capi.cpp "ensemble checkpoints"), two generations alternating
+ * so that a kill in mid-write loses nothing.  resume != 0: sub-batches with a complete checkpoint in the directory
+ * continue from it (finished ones only hand back their rows; their members are not even placed); the others start
+ * afresh.  The resumed run's rows (and final states of the sub-batches that still ran) equal the uninterrupted
+ * run's bit for bit.  The directory belongs to one (nmembers, sub_batch) decomposition; Run needs `out`. */
+void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *common_overrides,
+                                           const char **member_overrides, int nmembers, int sub_batch, int host_threads,
+                                           int keep_final_states, const char *checkpoint_dir, int resume);
 long pbEnsemblePipelineRun(void *pipeline, long max_steps, float *out, int max_rows, int *rows,
                            pbEnsembleTimings *timings);
 void pbEnsemblePipelineDestroy(void *pipeline);

@@ -2,6 +2,7 @@
 // scripts and tests can drive it through ctypes.  Exported from libparticlebot_host.so.
 #include <gnu/libc-version.h>
 #include <sched.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <atomic>
@@ -317,11 +318,23 @@ void pbHostLibcRandDraws(unsigned seed, int n, int *out) {
 namespace {
 
 // one member: its resolved configuration and the HostOnly object that places it and draws its dead set
+// what an ensemble checkpoint holds of one member beyond the host mirrors (pbEnsemblePipelineSetCheckpoint)
+struct MemberSaved {
+  float time = 0.0f;
+  unsigned draws = 0;
+  int sorted = 0, finished = 0, nrows = 0;
+  long steps = 0;
+  std::vector<float> rows, absA, absR;
+  std::vector<unsigned> orig, keys;
+};
+
 struct Member {
   PbRunConfig *cfg = nullptr;
   Particlebot *bot = nullptr;
   bool deadDrawn = false;  // the dead set was drawn with the placement (a draw due at time 0)
+  MemberSaved *saved = nullptr;  // restored from a checkpoint instead of placed
   ~Member() {
+    delete saved;
     delete bot;
     delete cfg;
   }
@@ -330,7 +343,7 @@ struct Member {
 // Host side of one member: configuration, placement (Particlebot::reset) and -- when the draw is due at the very
 // first step -- the dead set, all from the member's PRIVATE random stream, so that it does not matter which thread
 // builds which member, or when.  Returns false if the .cfg cannot be read.
-bool buildMember(Member &m, const char *cfg_path, const char *common_overrides, const char *own_overrides) {
+bool configureMember(Member &m, const char *cfg_path, const char *common_overrides, const char *own_overrides) {
   m.cfg = new PbRunConfig();
   m.cfg->params.seed = 0;
   if (cfg_path && !m.cfg->loadFile(cfg_path)) return false;
@@ -342,6 +355,13 @@ bool buildMember(Member &m, const char *cfg_path, const char *common_overrides, 
   bot->setSquareLattice(m.cfg->square_lattice);
   bot->setFastBlob(m.cfg->fast_blob);
   bot->setRng(m.cfg->rng_kind);
+  m.bot = bot;
+  return true;
+}
+
+bool buildMember(Member &m, const char *cfg_path, const char *common_overrides, const char *own_overrides) {
+  if (!configureMember(m, cfg_path, common_overrides, own_overrides)) return false;
+  Particlebot *bot = m.bot;
   bot->reset();
   bot->setHostTime(0.0f);
   if (bot->deadDrawDue(m.cfg->timestep)) {  // particlebot.cpp:178: drawn at the top of the first update()
@@ -368,12 +388,94 @@ unsigned hostThreads(int wanted) {
   return std::max(1u, std::min(nthreads, 128u));
 }
 
+// ---- ensemble checkpoints (pbEnsemblePipelineSetCheckpoint) ------------------------------------------------------
+// DIR/sub_<b>.manifest  "generation rows finished steps" of sub-batch b, written (tmp + rename) AFTER the member files
+//                       of that generation are complete: the members of one sub-batch share a clock, so a
+//                       checkpoint is only usable when all of them are from the same row
+// DIR/member_<k>.<generation>  header, the member's summary rows so far and -- unless it has finished -- every state
+//                       array, the stale slot layout and both generators (the exact checkpoint of class Particlebot,
+//                       per member of a batch).  Generations alternate 0/1 so that the previous complete one survives
+//                       a kill in the middle of writing the next.
+struct MemberFileHeader {
+  char magic[8];
+  uint32_t nbots;
+  float time;
+  uint32_t draws;
+  int32_t rngKind, sorted, deadDrawn, nrows, finished;
+  int32_t rs[36];
+};
+const char kMemberMagic[8] = {'P', 'B', 'E', 'N', 'S', 'M', '1', 0};
+
+std::string memberPath(const std::string &dir, int k, int gen) {
+  char name[64];
+  snprintf(name, sizeof name, "/member_%06d.%d", k, gen);
+  return dir + name;
+}
+std::string manifestPath(const std::string &dir, int sub) {
+  char name[64];
+  snprintf(name, sizeof name, "/sub_%06d.manifest", sub);
+  return dir + name;
+}
+
+template <class T>
+bool putv(FILE *fp, const T *p, size_t count) { return fwrite(p, sizeof(T), count, fp) == count; }
+template <class T>
+bool getv(FILE *fp, T *p, size_t count) { return fread(p, sizeof(T), count, fp) == count; }
+
+bool readManifest(const std::string &dir, int sub, int &gen, int &nrows, int &finished, long &steps) {
+  FILE *f = fopen(manifestPath(dir, sub).c_str(), "r");
+  if (!f) return false;
+  const bool ok = fscanf(f, "%d %d %d %ld", &gen, &nrows, &finished, &steps) == 4 && (gen == 0 || gen == 1);
+  fclose(f);
+  return ok;
+}
+
+// the member's file of generation gen -> m.saved (+ host mirrors, generator, dead-draw flag); false if unusable
+bool loadMemberFile(Member &m, const std::string &dir, int k, int gen, int wantRows, long steps) {
+  FILE *f = fopen(memberPath(dir, k, gen).c_str(), "rb");
+  if (!f) return false;
+  MemberFileHeader h;
+  const size_t n = m.bot->getParams().nCells;
+  MemberSaved *sv = new MemberSaved();
+  bool ok = getv(f, &h, 1) && memcmp(h.magic, kMemberMagic, 8) == 0 && h.nbots == n && h.nrows == wantRows &&
+            h.rngKind == m.cfg->rng_kind;
+  if (ok) {
+    sv->rows.resize((size_t)h.nrows * 4);
+    ok = getv(f, sv->rows.data(), sv->rows.size());
+  }
+  if (ok && !h.finished) {
+    std::vector<float> pos(2 * n), vel(2 * n), rad(n), phase(n);
+    std::vector<int> dead(n);
+    sv->absA.resize(n), sv->absR.resize(n), sv->orig.resize(n), sv->keys.resize(n);
+    ok = getv(f, pos.data(), 2 * n) && getv(f, vel.data(), 2 * n) && getv(f, rad.data(), n) &&
+         getv(f, phase.data(), n) && getv(f, dead.data(), n) && getv(f, sv->absA.data(), n) &&
+         getv(f, sv->absR.data(), n) && getv(f, sv->orig.data(), n) && getv(f, sv->keys.data(), n);
+    if (ok) m.bot->restoreHostMirrors(pos.data(), vel.data(), rad.data(), phase.data(), dead.data());
+  }
+  fclose(f);
+  if (!ok) {
+    delete sv;
+    return false;
+  }
+  sv->time = h.time, sv->draws = h.draws, sv->sorted = h.sorted, sv->finished = h.finished, sv->nrows = h.nrows;
+  sv->steps = steps;
+  m.bot->setHostRngState(h.rs);
+  m.bot->setHostTime(h.time);
+  m.deadDrawn = h.deadDrawn != 0;
+  m.saved = sv;
+  return true;
+}
+
 // A batch of members on the device: ONE pbSim, one launch per timestep.
 struct Ensemble {
   std::vector<Member *> members;  // owned
   pbSim *sim = nullptr;
   bool haveRow = false;  // runSteps: a summary row has been written at time rowTime
   float rowTime = 0.0f;
+  // checkpointing (pipeline): directory, this sub-batch's number and first member, steps done before this call
+  std::string ckptDir;
+  int ckptSub = 0, ckptFirst = 0, ckptGen = 0;
+  long stepsBefore = 0;
   ~Ensemble() {
     if (sim) pbSimDestroy(sim);
     for (auto *m : members) delete m;
@@ -394,6 +496,80 @@ bool uploadEnsemble(Ensemble *e) {
                         b->hostDead()) != PB_OK)
       return false;
   }
+  return true;
+}
+
+// writes generation (gen ^ 1) of every member of the batch (state as of now, `nrows` rows each), then the manifest
+bool saveSubBatch(Ensemble *e, const float *out, int max_rows, int nrows, long steps, bool finished) {
+  const int m = (int)e->members.size();
+  const int gen = e->ckptGen ^ 1;
+  const size_t n = e->members[0]->bot->getParams().nCells;
+  float t = 0.0f;
+  unsigned draws = 0;
+  if (pbSimGetTime(e->sim, &t) != PB_OK || pbSimGetPhaseDraws(e->sim, &draws) != PB_OK) return false;
+  std::vector<float> pos(2 * n), vel(2 * n), rad(n), phase(n), absA(n), absR(n);
+  std::vector<int> dead(n);
+  std::vector<unsigned> orig(n), keys(n);
+  pbSimConfig conf;
+  if (pbSimGetConfig(e->sim, &conf) != PB_OK) return false;
+  for (int k = 0; k < m; k++) {
+    MemberFileHeader h;
+    memcpy(h.magic, kMemberMagic, 8);
+    h.nbots = (uint32_t)n, h.time = t, h.draws = draws, h.rngKind = e->members[k]->cfg->rng_kind;
+    h.deadDrawn = e->members[k]->deadDrawn ? 1 : 0, h.nrows = nrows, h.finished = finished ? 1 : 0;
+    int sorted = 0;
+    if (!finished) {
+      if (pbSimGetStateOf(e->sim, (unsigned)k, pos.data(), vel.data(), rad.data(), phase.data(), dead.data(), absA.data(),
+                          absR.data()) != PB_OK ||
+          pbSimGetLayoutOf(e->sim, (unsigned)k, orig.data(), keys.data(), &sorted) != PB_OK)
+        return false;
+      if (!conf.attraction_sums) std::fill(absA.begin(), absA.end(), 0.0f);  // (not maintained: never NaN on disk)
+    }
+    h.sorted = sorted;
+    e->members[k]->bot->getHostRngState(h.rs);
+    const std::string dest = memberPath(e->ckptDir, e->ckptFirst + k, gen), tmp = dest + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    bool ok = f && putv(f, &h, 1) && putv(f, out + (size_t)k * max_rows * 4, (size_t)nrows * 4);
+    if (ok && !finished)
+      ok = putv(f, pos.data(), 2 * n) && putv(f, vel.data(), 2 * n) && putv(f, rad.data(), n) && putv(f, phase.data(), n) &&
+           putv(f, dead.data(), n) && putv(f, absA.data(), n) && putv(f, absR.data(), n) && putv(f, orig.data(), n) &&
+           putv(f, keys.data(), n);
+    if (f) ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), dest.c_str()) != 0) return false;
+  }
+  const std::string dest = manifestPath(e->ckptDir, e->ckptSub), tmp = dest + ".tmp";
+  FILE *f = fopen(tmp.c_str(), "w");
+  bool ok = f && fprintf(f, "%d %d %d %ld\n", gen, nrows, finished ? 1 : 0, steps) > 0;
+  if (f) ok = (fclose(f) == 0) && ok;
+  if (!ok || rename(tmp.c_str(), dest.c_str()) != 0) return false;
+  e->ckptGen = gen;
+  return true;
+}
+
+// device side of a sub-batch whose members were restored from a checkpoint (all from the same row)
+bool uploadRestored(Ensemble *e, float *out, int max_rows) {
+  if (!uploadEnsemble(e)) return false;  // (the host mirrors hold the restored state)
+  const int m = (int)e->members.size();
+  const MemberSaved &s0 = *e->members[0]->saved;
+  for (int k = 0; k < m; k++) {
+    const MemberSaved &sv = *e->members[k]->saved;
+    if (sv.time != s0.time || sv.draws != s0.draws || sv.sorted != s0.sorted || sv.nrows != s0.nrows) return false;
+    if (sv.sorted && pbSimSetLayoutOf(e->sim, (unsigned)k, sv.orig.data(), sv.keys.data()) != PB_OK) return false;
+  }
+  for (int k = 0; k < m; k++) {
+    // (the layout is installed once every member has provided one: the state goes in afterwards, in that order)
+    const Member &mk = *e->members[k];
+    const Particlebot *b = mk.bot;
+    if (pbSimSetStateOf(e->sim, (unsigned)k, b->hostPositions(), b->hostVelocities(), b->hostRadii(), b->hostPhases(),
+                        b->hostDead()) != PB_OK ||
+        pbSimSetForcesOf(e->sim, (unsigned)k, mk.saved->absA.data(), mk.saved->absR.data()) != PB_OK)
+      return false;
+    if (out) memcpy(out + (size_t)k * max_rows * 4, mk.saved->rows.data(), sizeof(float) * mk.saved->rows.size());
+  }
+  if (pbSimSetTime(e->sim, s0.time) != PB_OK || pbSimSetPhaseDraws(e->sim, s0.draws) != PB_OK) return false;
+  e->haveRow = true;  // the row at the checkpoint's time is among the restored ones
+  e->rowTime = s0.time;
+  e->stepsBefore = s0.steps;
   return true;
 }
 
@@ -426,6 +602,11 @@ long runSteps(Ensemble *e, long max_steps, float *out, int max_rows, int *rows) 
       nrows++;
       e->haveRow = true;
       e->rowTime = t;
+      if (!e->ckptDir.empty() &&
+          !saveSubBatch(e, out, max_rows, nrows, e->stepsBefore + steps, t > c0.params.max_time)) {
+        fprintf(stderr, "pbEnsemble: cannot write the checkpoint of sub-batch %d under %s\n", e->ckptSub, e->ckptDir.c_str());
+        return -1;
+      }
     }
     if (t > c0.params.max_time || steps >= max_steps) break;
     // host events at this step: dead-bot draws (those due at time 0 came with the placement)
@@ -492,6 +673,9 @@ struct Pipeline {
   unsigned nbots = 0;
   pbEnsembleTimings tm{};
   std::vector<double> cpuSeconds;  // per producer thread
+  std::string ckptDir;  // checkpoints (pbEnsemblePipelineSetCheckpoint); empty: none
+  bool resume = false;
+  bool started = false;
 
   void producer(int tid) {
     for (;;) {
@@ -505,8 +689,26 @@ struct Pipeline {
       }
       const double t0 = nowSeconds();
       Member *m = new Member();
-      const bool ok = buildMember(*m, haveCfg ? cfgPath.c_str() : nullptr, common.empty() ? nullptr : common.c_str(),
-                                  over[k].c_str());
+      const char *cp = haveCfg ? cfgPath.c_str() : nullptr, *co = common.empty() ? nullptr : common.c_str();
+      bool ok = true, restored = false;
+      if (resume) {
+        // a member whose sub-batch has a complete checkpoint is restored, not placed
+        int gen = 0, nrows = 0, finished = 0;
+        long steps = 0;
+        if (readManifest(ckptDir, k / sub, gen, nrows, finished, steps)) {
+          ok = configureMember(*m, cp, co, over[k].c_str());
+          restored = ok && loadMemberFile(*m, ckptDir, k, gen, nrows, steps);
+          if (ok && !restored) {
+            fprintf(stderr, "pbEnsemblePipeline: checkpoint of member %d under %s is unusable\n", k, ckptDir.c_str());
+            ok = false;
+          }
+        }
+      }
+      if (ok && !restored) {
+        delete m;
+        m = new Member();
+        ok = buildMember(*m, cp, co, over[k].c_str());
+      }
       cpuSeconds[tid] += nowSeconds() - t0;
       std::lock_guard<std::mutex> lock(mu);
       if (!ok) {
@@ -600,8 +802,9 @@ long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
 }
 
 // ---- pipelined ensembles (include/particlebot_ensemble.h) ------------------------------------------------------
-void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
-                               int nmembers, int sub_batch, int host_threads, int keep_final_states) {
+void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *common_overrides,
+                                           const char **member_overrides, int nmembers, int sub_batch, int host_threads,
+                                           int keep_final_states, const char *checkpoint_dir, int resume) {
   if (nmembers < 1) return nullptr;
   Pipeline *p = new Pipeline();
   p->haveCfg = cfg_path != nullptr;
@@ -623,8 +826,44 @@ void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_override
   }
   p->tm.host_threads = p->threads;
   p->tm.sub_batch = p->sub;
+  if (checkpoint_dir && checkpoint_dir[0]) {
+    p->ckptDir = checkpoint_dir;
+    p->resume = resume != 0;
+    (void)mkdir(checkpoint_dir, 0777);
+    // a checkpoint directory belongs to ONE decomposition of the ensemble
+    const std::string info = p->ckptDir + "/run.info";
+    char want[128];
+    snprintf(want, sizeof want, "members %d sub_batch %d\n", nmembers, p->sub);
+    if (p->resume) {
+      char got[128] = {0};
+      FILE *f = fopen(info.c_str(), "r");
+      const bool same = f && fgets(got, sizeof got, f) && strcmp(got, want) == 0;
+      if (f) fclose(f);
+      if (!same) {
+        fprintf(stderr, "pbEnsemblePipeline: %s was written for another decomposition (%s) than this one (%s)\n",
+                checkpoint_dir, got, want);
+        delete p;
+        return nullptr;
+      }
+    } else {
+      FILE *f = fopen(info.c_str(), "w");
+      if (!f || fputs(want, f) < 0 || fclose(f) != 0) {
+        fprintf(stderr, "pbEnsemblePipeline: cannot write under %s\n", checkpoint_dir);
+        delete p;
+        return nullptr;
+      }
+      // (manifests of an earlier run in the same directory must not be mistaken for this run's)
+      for (int b = 0; b * p->sub < nmembers; b++) (void)remove(manifestPath(p->ckptDir, b).c_str());
+    }
+  }
   p->start();  // placement starts now, before the caller asks for the first step
   return p;
+}
+
+void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
+                               int nmembers, int sub_batch, int host_threads, int keep_final_states) {
+  return pbEnsemblePipelineCreateCheckpointed(cfg_path, common_overrides, member_overrides, nmembers, sub_batch,
+                                              host_threads, keep_final_states, nullptr, 0);
 }
 
 void pbEnsemblePipelineDestroy(void *pv) { delete (Pipeline *)pv; }
@@ -657,17 +896,60 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
     }
     p->cvRoom.notify_all();
     const double u0 = nowSeconds();
-    if (!uploadEnsemble(&e)) {
-      fprintf(stderr, "pbEnsemblePipelineRun: %s\n", pbGetLastErrorString());
+    float *const outSub = out ? out + (size_t)first * max_rows * 4 : nullptr;
+    p->nbots = e.members[0]->bot->getParams().nCells;
+    // restored from a checkpoint?  (all members of a sub-batch or none: they share one manifest)
+    int nRestored = 0;
+    for (Member *mk : e.members) nRestored += mk->saved ? 1 : 0;
+    if (nRestored != 0 && nRestored != count) {
+      fprintf(stderr, "pbEnsemblePipelineRun: sub-batch %d is only partly in the checkpoint\n", first / p->sub);
       return -1;
     }
-    p->nbots = e.members[0]->bot->getParams().nCells;
-    const double d0 = nowSeconds();
-    p->tm.upload_s += d0 - u0;
+    e.ckptDir = p->ckptDir;
+    e.ckptSub = first / p->sub;
+    e.ckptFirst = first;
+    long done = 0;
     int nrows = 0;
-    const long done = runSteps(&e, max_steps, out ? out + (size_t)first * max_rows * 4 : nullptr, max_rows, &nrows);
-    if (done < 0 || pbSimSynchronize(e.sim) != PB_OK) return -1;
-    if (p->keepStates)
+    if (nRestored && e.members[0]->saved->finished) {
+      // nothing left to run: the rows are the result
+      const MemberSaved &s0 = *e.members[0]->saved;
+      nrows = s0.nrows;
+      done = s0.steps;
+      if (nrows > max_rows) return -1;
+      for (int k = 0; k < count && outSub; k++)
+        memcpy(outSub + (size_t)k * max_rows * 4, e.members[k]->saved->rows.data(), sizeof(float) * 4 * (size_t)nrows);
+      p->tm.upload_s += nowSeconds() - u0;
+    } else {
+      if (nRestored) {
+        int gen = 0, r0 = 0, fin = 0;
+        long st = 0;
+        (void)readManifest(p->ckptDir, e.ckptSub, gen, r0, fin, st);
+        e.ckptGen = gen;
+        nrows = e.members[0]->saved->nrows;
+        if (nrows > max_rows || !outSub) return -1;
+      }
+      if (nRestored ? !uploadRestored(&e, outSub, max_rows) : !uploadEnsemble(&e)) {
+        fprintf(stderr, "pbEnsemblePipelineRun: %s\n", pbGetLastErrorString());
+        return -1;
+      }
+      const double d0 = nowSeconds();
+      p->tm.upload_s += d0 - u0;
+      const long more = runSteps(&e, max_steps - e.stepsBefore, outSub, max_rows, &nrows);
+      if (more < 0 || pbSimSynchronize(e.sim) != PB_OK) return -1;
+      done = e.stepsBefore + more;
+      if (!p->ckptDir.empty()) {
+        // the end of this sub-batch's run: finished (past max_time) or stopped by max_steps (resumable)
+        float tEnd = 0.0f;
+        if (pbSimGetTime(e.sim, &tEnd) != PB_OK) return -1;
+        const bool finished = tEnd > e.members[0]->cfg->params.max_time;
+        if (!outSub || !saveSubBatch(&e, outSub, max_rows, nrows, done, finished)) {
+          fprintf(stderr, "pbEnsemblePipelineRun: cannot write the checkpoint of sub-batch %d\n", e.ckptSub);
+          return -1;
+        }
+      }
+      p->tm.device_s += nowSeconds() - d0;
+    }
+    if (p->keepStates && e.sim)
       for (int k = 0; k < count; k++) {
         const size_t n = p->nbots;
         p->finalPos[first + k].resize(2 * n);
@@ -677,7 +959,6 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
                             p->finalRad[first + k].data(), nullptr, nullptr, nullptr, nullptr) != PB_OK)
           return -1;
       }
-    p->tm.device_s += nowSeconds() - d0;
     if (first == 0) {
       steps = done;
       nrowsAll = nrows;

@@ -3,25 +3,36 @@
 // with one ncclAllGather over RCCL/xGMI (include/particlebot_ensemble.h).
 //
 //   particlebot_ensemble <config.cfg> --members M [--seed0 S] [--set NAME VALUE]...
-//                        [--sweep KEY V1 V2 ...] [--out FILE] [--rendezvous FILE]
+//                        [--sweep KEY V1 V2 ...] [--out FILE] [--sub-batch B] [--host-threads T]
+//                        [--checkpoint DIR | --resume DIR] [--rendezvous FILE]
 //
 // Launch with any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (torchrun), OMPI_COMM_WORLD_* or
 // SLURM_PROCID / SLURM_NTASKS / SLURM_LOCALID, or by hand:  RANK=r WORLD_SIZE=N LOCAL_RANK=r ...
-// Member k (seed seed0 + k, sweep value V[k mod #V]) runs on rank k mod N.  Rank 0 creates the RCCL
-// unique id and publishes it through the rendezvous file (default /tmp/particlebot_ensemble_<port>.id
-// with <port> = $MASTER_PORT or 0; written to a temporary name and renamed, the other ranks poll).
-// Rank 0 prints one JSON line and, with --out, writes the gathered rows as float32 [M][rows][4].
+// Member k (seed seed0 + k, sweep value V[k mod #V]) runs on rank k mod N.  A rank's members run through the
+// placement/stepping pipeline (pbEnsemblePipeline*): sub-batches of B members, the host placing the next ones
+// while the device steps the current one.  --checkpoint DIR saves every member exactly at each summary row
+// (DIR/rank<r>/...); --resume DIR continues a killed sweep from there (same M, N and B), bit-identically.
+//
+// Rendezvous: rank 0 creates the RCCL unique id and serves it over TCP on MASTER_ADDR:MASTER_PORT (default
+// 127.0.0.1:29400) to the other ranks, which retry until it listens -- nothing left behind on disk, nothing a
+// crashed earlier launch could have left either.  --rendezvous FILE exchanges it through that file instead
+// (written to a temporary name and renamed; taken only if rank 0's process, whose id it carries, is alive).
+// A rank that fails still takes part in the collectives: an error flag is reduced first, then all ranks leave.
+#include <arpa/inet.h>
 #include <hip/hip_runtime.h>
+#include <netinet/in.h>
 #include <rccl/rccl.h>
+#include <signal.h>
+#include <sys/socket.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <ctime>
 #include <limits>
 #include <string>
 #include <thread>
@@ -55,27 +66,112 @@ static int envInt(const char *const *names, int fallback) {
   return fallback;
 }
 
+// ---- rendezvous over TCP ---------------------------------------------------------------------------------------
+static bool sendAll(int fd, const void *p, size_t n) {
+  const char *c = (const char *)p;
+  while (n) {
+    const ssize_t k = send(fd, c, n, MSG_NOSIGNAL);
+    if (k <= 0) return false;
+    c += k, n -= (size_t)k;
+  }
+  return true;
+}
+static bool recvAll(int fd, void *p, size_t n) {
+  char *c = (char *)p;
+  while (n) {
+    const ssize_t k = recv(fd, c, n, 0);
+    if (k <= 0) return false;
+    c += k, n -= (size_t)k;
+  }
+  return true;
+}
+
+// rank 0: listen, hand the id to world - 1 peers (each says "PBID" + its rank first)
+static bool serveId(const char *addr, int port, int world, const ncclUniqueId &id, double timeoutSeconds) {
+  const int ls = socket(AF_INET, SOCK_STREAM, 0);
+  if (ls < 0) return false;
+  int one = 1;
+  setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+  sockaddr_in sa{};
+  sa.sin_family = AF_INET;
+  sa.sin_port = htons((uint16_t)port);
+  if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+  if (bind(ls, (sockaddr *)&sa, sizeof sa) != 0 || listen(ls, world) != 0) {
+    close(ls);
+    return false;
+  }
+  timeval tv{(time_t)timeoutSeconds, 0};
+  setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+  std::vector<char> served(world, 0);
+  int left = world - 1;
+  while (left > 0) {
+    const int fd = accept(ls, nullptr, nullptr);
+    if (fd < 0) break;  // timed out
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    char hello[4];
+    int32_t r = -1;
+    if (recvAll(fd, hello, 4) && memcmp(hello, "PBID", 4) == 0 && recvAll(fd, &r, 4) && r > 0 && r < world &&
+        sendAll(fd, &id, sizeof id) && !served[r]) {
+      served[r] = 1;
+      left--;
+    }
+    close(fd);
+  }
+  close(ls);
+  return left == 0;
+}
+
+static bool fetchIdTcp(const char *addr, int port, int rank, ncclUniqueId *id, double timeoutSeconds) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const int fd = socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) return false;
+    sockaddr_in sa{};
+    sa.sin_family = AF_INET;
+    sa.sin_port = htons((uint16_t)port);
+    if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+    if (connect(fd, (sockaddr *)&sa, sizeof sa) == 0) {
+      const int32_t r = rank;
+      const bool ok = sendAll(fd, "PBID", 4) && sendAll(fd, &r, 4) && recvAll(fd, id, sizeof *id);
+      close(fd);
+      if (ok) return true;
+    } else {
+      close(fd);
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSeconds) return false;
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  }
+}
+
+// ---- rendezvous through a file (only on request) ------------------------------------------------------------------
+struct IdFile {
+  char magic[8];
+  int32_t pid;  // rank 0's process: a file whose writer is gone is stale
+  ncclUniqueId id;
+};
 static bool publishId(const std::string &path, const ncclUniqueId &id) {
+  (void)remove(path.c_str());  // whatever an earlier launch left
   const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
   FILE *f = fopen(tmp.c_str(), "wb");
   if (!f) return false;
-  const bool ok = fwrite(&id, sizeof id, 1, f) == 1;
+  IdFile rec;
+  memcpy(rec.magic, "PBIDF1\0", 8);
+  rec.pid = (int32_t)getpid();
+  rec.id = id;
+  const bool ok = fwrite(&rec, sizeof rec, 1, f) == 1;
   if (fclose(f) != 0 || !ok) return false;
   return rename(tmp.c_str(), path.c_str()) == 0;
 }
-
-// A file left behind by an earlier, crashed launch with the same port must not be taken for this
-// launch's id: only a file written no earlier than a minute before this process started counts.
-static bool fetchId(const std::string &path, ncclUniqueId *id, double timeoutSeconds) {
+static bool fetchIdFile(const std::string &path, ncclUniqueId *id, double timeoutSeconds) {
   const auto t0 = std::chrono::steady_clock::now();
-  const time_t started = time(nullptr);
   for (;;) {
-    struct stat sb;
-    if (stat(path.c_str(), &sb) == 0 && sb.st_mtime >= started - 60) {
-      if (FILE *f = fopen(path.c_str(), "rb")) {
-        const bool ok = fread(id, sizeof *id, 1, f) == 1;
-        fclose(f);
-        if (ok) return true;
+    if (FILE *f = fopen(path.c_str(), "rb")) {
+      IdFile rec;
+      const bool ok = fread(&rec, sizeof rec, 1, f) == 1 && memcmp(rec.magic, "PBIDF1\0", 8) == 0;
+      fclose(f);
+      if (ok && rec.pid > 0 && (kill(rec.pid, 0) == 0 || errno == EPERM)) {  // its writer is still running
+        *id = rec.id;
+        return true;
       }
     }
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSeconds) return false;
@@ -84,18 +180,25 @@ static bool fetchId(const std::string &path, ncclUniqueId *id, double timeoutSec
 }
 
 int main(int argc, char **argv) {
-  std::string cfgPath, outPath, rendezvous;
+  std::string cfgPath, outPath, rendezvous, ckptDir;
   std::vector<std::pair<std::string, std::string>> sets;
   std::string sweepKey;
   std::vector<std::string> sweepVals;
-  int members = 32;
+  int members = 32, subBatch = 0, hostThreads = 0;
+  bool resume = false;
   long seed0 = 1000;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--members") && i + 1 < argc) members = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--seed0") && i + 1 < argc) seed0 = atol(argv[++i]);
     else if (!strcmp(argv[i], "--out") && i + 1 < argc) outPath = argv[++i];
     else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc) rendezvous = argv[++i];
-    else if (!strcmp(argv[i], "--set") && i + 2 < argc) {
+    else if (!strcmp(argv[i], "--sub-batch") && i + 1 < argc) subBatch = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) hostThreads = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--checkpoint") && i + 1 < argc) ckptDir = argv[++i];
+    else if (!strcmp(argv[i], "--resume") && i + 1 < argc) {
+      ckptDir = argv[++i];
+      resume = true;
+    } else if (!strcmp(argv[i], "--set") && i + 2 < argc) {
       sets.emplace_back(argv[i + 1], argv[i + 2]);
       i += 2;
     } else if (!strcmp(argv[i], "--sweep") && i + 2 < argc) {
@@ -103,8 +206,9 @@ int main(int argc, char **argv) {
       while (i + 1 < argc && strncmp(argv[i + 1], "--", 2) != 0) sweepVals.push_back(argv[++i]);
     } else if (argv[i][0] != '-' && cfgPath.empty()) cfgPath = argv[i];
     else {
-      fprintf(stderr, "usage: %s <config.cfg> --members M [--seed0 S] [--set NAME VALUE]... "
-                      "[--sweep KEY V1 V2 ...] [--out FILE] [--rendezvous FILE]\n", argv[0]);
+      fprintf(stderr, "usage: %s <config.cfg> --members M [--seed0 S] [--set NAME VALUE]... [--sweep KEY V1 V2 ...] "
+                      "[--out FILE] [--sub-batch B] [--host-threads T] [--checkpoint DIR | --resume DIR] "
+                      "[--rendezvous FILE]\n", argv[0]);
       return 2;
     }
   }
@@ -130,20 +234,28 @@ int main(int argc, char **argv) {
   CHECK_HIP(hipSetDevice(local % ndev));
 
   // ---- RCCL communicator: one rank per GPU -----------------------------------------------------
-  if (rendezvous.empty()) {
-    const char *port = getenv("MASTER_PORT");
-    rendezvous = std::string("/tmp/particlebot_ensemble_") + (port ? port : "0") + ".id";
-  }
   ncclUniqueId id;
+  const char *addr = getenv("MASTER_ADDR");
+  const char *portText = getenv("MASTER_PORT");
+  const int port = portText ? atoi(portText) : 29400;
   if (rank == 0) {
     CHECK_NCCL(ncclGetUniqueId(&id));
-    if (world > 1 && !publishId(rendezvous, id)) {
-      fprintf(stderr, "rank 0: cannot write the rendezvous file %s\n", rendezvous.c_str());
+    if (world > 1) {
+      const bool ok = rendezvous.empty() ? serveId(addr ? addr : "127.0.0.1", port, world, id, 120.0)
+                                         : publishId(rendezvous, id);
+      if (!ok) {
+        fprintf(stderr, "rank 0: rendezvous failed (%s)\n",
+                rendezvous.empty() ? "could not serve the RCCL id to every rank over TCP" : rendezvous.c_str());
+        return 1;
+      }
+    }
+  } else {
+    const bool ok = rendezvous.empty() ? fetchIdTcp(addr ? addr : "127.0.0.1", port, rank, &id, 120.0)
+                                       : fetchIdFile(rendezvous, &id, 120.0);
+    if (!ok) {
+      fprintf(stderr, "rank %d: no RCCL id from rank 0 after 120 s\n", rank);
       return 1;
     }
-  } else if (!fetchId(rendezvous, &id, 120.0)) {
-    fprintf(stderr, "rank %d: no RCCL id in %s after 120 s\n", rank, rendezvous.c_str());
-    return 1;
   }
   ncclComm_t comm;
   CHECK_NCCL(ncclCommInitRank(&comm, world, id, rank));
@@ -164,34 +276,52 @@ int main(int argc, char **argv) {
   const int mine = (int)over.size(), per = pbEnsembleShard(members, 0, world);
   const int maxRows = 4096;
   std::vector<float> rows((size_t)(mine ? mine : 1) * maxRows * 4, 0.0f);
-  int nrows = 0;
+  int nrows = 0, failed = 0;
   long steps = 0;
   unsigned nbots = 0;
+  pbEnsembleTimings tm{};
   const auto t0 = std::chrono::steady_clock::now();
   if (mine > 0) {
-    void *e = pbEnsembleCreate(cfgPath.c_str(), common.empty() ? nullptr : common.c_str(), overPtr.data(), mine);
-    if (!e) {
-      fprintf(stderr, "rank %d: pbEnsembleCreate failed\n", rank);
-      return 1;
+    std::string myCkpt;
+    if (!ckptDir.empty()) {
+      (void)mkdir(ckptDir.c_str(), 0777);
+      myCkpt = ckptDir + "/rank" + std::to_string(rank) + "of" + std::to_string(world);
     }
-    nbots = pbEnsembleNumBots(e);
-    steps = pbEnsembleRun(e, rows.data(), maxRows, &nrows);
-    pbEnsembleDestroy(e);
-    if (steps < 0) {
-      fprintf(stderr, "rank %d: pbEnsembleRun failed\n", rank);
-      return 1;
+    void *e = pbEnsemblePipelineCreateCheckpointed(cfgPath.c_str(), common.empty() ? nullptr : common.c_str(),
+                                                   overPtr.data(), mine, subBatch, hostThreads, 0,
+                                                   myCkpt.empty() ? nullptr : myCkpt.c_str(), resume ? 1 : 0);
+    if (!e) {
+      fprintf(stderr, "rank %d: pbEnsemblePipelineCreate failed\n", rank);
+      failed = 1;
+    } else {
+      steps = pbEnsemblePipelineRun(e, (long)1 << 62, rows.data(), maxRows, &nrows, &tm);
+      nbots = pbEnsemblePipelineNumBots(e);
+      pbEnsemblePipelineDestroy(e);
+      if (steps < 0) {
+        fprintf(stderr, "rank %d: pbEnsemblePipelineRun failed\n", rank);
+        failed = 1;
+        steps = 0;
+        nrows = 0;
+      }
     }
   }
   double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
-  // ---- the one exchange: summary rows (plus three scalars), over RCCL ----------------------------
-  // scalars first: max wall time, max row count, bots per member, steps (ranks without members send 0)
-  double hs[4] = {wall, (double)nrows, (double)nbots, (double)steps}, *ds = nullptr;
+  // ---- the one exchange: summary rows (plus a few scalars), over RCCL ----------------------------
+  // scalars first, by max: wall time, row count, bots per member, steps, ERROR FLAG (every rank gets here,
+  // whatever happened to its members, so that no rank waits in a collective for one that has left)
+  double hs[5] = {wall, (double)nrows, (double)nbots, (double)steps, (double)failed}, *ds = nullptr;
   CHECK_HIP(hipMalloc((void **)&ds, sizeof hs));
   CHECK_HIP(hipMemcpyAsync(ds, hs, sizeof hs, hipMemcpyHostToDevice, stream));
-  CHECK_NCCL(ncclAllReduce(ds, ds, 4, ncclDouble, ncclMax, comm, stream));
+  CHECK_NCCL(ncclAllReduce(ds, ds, 5, ncclDouble, ncclMax, comm, stream));
   CHECK_HIP(hipMemcpyAsync(hs, ds, sizeof hs, hipMemcpyDeviceToHost, stream));
   CHECK_HIP(hipStreamSynchronize(stream));
+  if (hs[4] != 0.0) {
+    if (rank == 0) fprintf(stderr, "particlebot_ensemble: a rank failed; no result\n");
+    (void)hipFree(ds);
+    ncclCommDestroy(comm);
+    return 1;
+  }
   wall = hs[0];
   const int allRows = (int)hs[1];
   const size_t block = (size_t)per * allRows * 4;
@@ -213,7 +343,7 @@ int main(int argc, char **argv) {
   if (rank == 0) {
     // progress of each member's centre of mass toward the light = decrease of the distance column
     double sum = 0, sum2 = 0;
-    for (int k = 0; k < members; k++) {
+    for (int k = 0; k < members && allRows > 0; k++) {
       const float *first = &all[((size_t)k * allRows) * 4], *last = &all[((size_t)k * allRows + allRows - 1) * 4];
       const double d = (double)first[3] - (double)last[3];
       sum += d;
@@ -223,9 +353,13 @@ int main(int argc, char **argv) {
     printf("{\"cfg\": \"%s\", \"members\": %d, \"n_gpus\": %d, \"bots_per_member\": %d, \"steps_per_member\": %ld, "
            "\"rows_per_member\": %d, \"wall_s\": %.6f, \"sims_per_s\": %.6g, \"particle_steps_per_s\": %.6g, "
            "\"progress_toward_light_mean\": %.9g, \"progress_toward_light_std\": %.9g, "
+           "\"pipeline_rank0\": {\"sub_batch\": %d, \"sub_batches\": %d, \"host_threads\": %d, \"placement_cpu_s\": %.4f, "
+           "\"placement_wait_s\": %.4f, \"upload_s\": %.4f, \"device_s\": %.4f}, \"resumed\": %s, "
            "\"collective\": \"ncclAllGather of %zu floats per rank (RCCL)\"}\n",
            cfgPath.c_str(), members, world, (int)hs[2], (long)hs[3], allRows, wall, members / wall,
-           (double)members * hs[2] * hs[3] / wall, mean, sqrt(var > 0 ? var : 0), block);
+           (double)members * hs[2] * hs[3] / wall, mean, sqrt(var > 0 ? var : 0), tm.sub_batch, tm.sub_batches,
+           tm.host_threads, tm.placement_cpu_s, tm.placement_wait_s, tm.upload_s, tm.device_s, resume ? "true" : "false",
+           block);
     if (!outPath.empty()) {
       FILE *f = fopen(outPath.c_str(), "wb");
       if (!f || fwrite(all.data(), sizeof(float), (size_t)members * allRows * 4, f) != (size_t)members * allRows * 4) {
@@ -234,7 +368,7 @@ int main(int argc, char **argv) {
       }
       if (f) fclose(f);
     }
-    if (world > 1) (void)remove(rendezvous.c_str());
+    if (world > 1 && !rendezvous.empty()) (void)remove(rendezvous.c_str());
   }
   (void)hipFree(ds);
   (void)hipFree(dSend);

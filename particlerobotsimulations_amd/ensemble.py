@@ -126,6 +126,9 @@ def _pipeline_lib():
     L.pbEnsemblePipelineCreate.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int,
                                            C.c_int]
     L.pbEnsemblePipelineCreate.restype = C.c_void_p
+    L.pbEnsemblePipelineCreateCheckpointed.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int,
+                                                       C.c_int, C.c_int, C.c_char_p, C.c_int]
+    L.pbEnsemblePipelineCreateCheckpointed.restype = C.c_void_p
     L.pbEnsemblePipelineRun.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                         C.POINTER(Timings)]
     L.pbEnsemblePipelineRun.restype = C.c_long
@@ -143,7 +146,7 @@ class PipelinedEnsemble:
     Placement starts in the constructor.  Rows and final states do not depend on sub_batch or host_threads."""
 
     def __init__(self, cfg_path, overrides_per_member, common=None, sub_batch=0, host_threads=0, max_rows=4096,
-                 keep_final_states=False):
+                 keep_final_states=False, checkpoint_dir=None, resume=False):
         self._L = _pipeline_lib()
         self.m = len(overrides_per_member)
         self.max_rows = max_rows
@@ -155,8 +158,10 @@ class PipelinedEnsemble:
             return
         arr = (C.c_char_p * self.m)(*[o.encode() for o in overrides_per_member])
         common_b = "\n".join(f"{k}\n{v}" for k, v in (common or {}).items()).encode() or None
-        self._h = self._L.pbEnsemblePipelineCreate(os.fsencode(cfg_path), common_b, arr, self.m, int(sub_batch),
-                                                   int(host_threads), 1 if keep_final_states else 0)
+        # checkpoint_dir: every member saved exactly at each summary row; resume: continue from what is there
+        self._h = self._L.pbEnsemblePipelineCreateCheckpointed(
+            os.fsencode(cfg_path), common_b, arr, self.m, int(sub_batch), int(host_threads),
+            1 if keep_final_states else 0, os.fsencode(checkpoint_dir) if checkpoint_dir else None, 1 if resume else 0)
         if not self._h:
             raise RuntimeError("pbEnsemblePipelineCreate failed")
 

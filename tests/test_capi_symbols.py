@@ -106,7 +106,9 @@ def test_ensemble_header_symbols_are_exported_by_the_host_library():
     names = {m.group(1) for m in re.finditer(r"\b(pbEnsemble\w+)\s*\(", text)}
     assert names == {"pbEnsembleCreate", "pbEnsembleDestroy", "pbEnsembleRun", "pbEnsembleRunSteps",
                      "pbEnsembleSynchronize", "pbEnsembleGetState", "pbEnsembleNumBots", "pbEnsembleShard",
-                     "pbEnsembleAssemble"}
+                     "pbEnsembleAssemble", "pbEnsemblePipelineCreate", "pbEnsemblePipelineCreateCheckpointed",
+                     "pbEnsemblePipelineRun", "pbEnsemblePipelineDestroy", "pbEnsemblePipelineNumBots",
+                     "pbEnsemblePipelineGetState", "pbEnsemblePipelineDryRun"}
     L = host.lib()
     for n in names:
         assert hasattr(L, n), n

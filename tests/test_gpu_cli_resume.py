@@ -95,3 +95,70 @@ def test_resume_from_the_csv_like_the_reference(tmp_path):
     t0, t1 = times(rows_before), times(rows[len(rows_before):])
     # (the resumed run dumps the row it restarted from again, as the reference's loop would)
     assert t1[0] == pytest.approx(t0[-1], abs=0.011) and t1[-1] >= 3.99 and t0[-1] <= 2.02
+
+
+def test_pipelined_ensemble_stopped_and_resumed_equals_the_uninterrupted_run(tmp_path):
+    """A 16-member ensemble in sub-batches of 8 with checkpoints at every summary row: stopped after 1500 of its
+    3000 steps (sub-batch 0 in mid-run, sub-batch 1 not started... both stop at the step cap), resumed: the same rows
+    bit for bit, the same final states; resumed once more after everything has finished: rows straight from disk."""
+    from helpers import assert_bit_equal
+    from particlerobotsimulations_amd import ensemble
+    cfg = EX("example_obstacle.cfg")
+    members = [f"seed\n{1000 + k}" for k in range(16)]
+    common = {"max_time": "30", "dump_interval": "6", "time_to_dead": "7", "nDead": "40"}
+    a = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=8, host_threads=2, keep_final_states=True,
+                                   checkpoint_dir=str(tmp_path / "a"))
+    steps = a.run()
+    assert steps in (3000, 3001) and a.rows.shape[1] == 7
+    b = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=8, host_threads=2, checkpoint_dir=str(tmp_path / "b"))
+    assert b.run(1500) == 1500
+    assert b.rows.shape[1] == 4          # t = 0, 0.01, 6, 12
+    b.close()
+    b2 = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=8, host_threads=2, keep_final_states=True,
+                                    checkpoint_dir=str(tmp_path / "b"), resume=True)
+    assert b2.run() == steps
+    assert np.array_equal(b2.rows.view(np.uint32), a.rows.view(np.uint32))
+    sa, sb = a.final_states(), b2.final_states()
+    for k in range(16):
+        for key in ("pos", "vel", "rad"):
+            assert_bit_equal(sb[k][key], sa[k][key], f"member {k} {key}")
+    assert b2.timings["placement_cpu_s"] < a.timings["placement_cpu_s"]      # restored, not placed again
+    b2.close()
+    b3 = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=8, host_threads=2, checkpoint_dir=str(tmp_path / "b"),
+                                    resume=True)
+    assert b3.run() == steps and b3.timings["device_s"] == 0.0
+    assert np.array_equal(b3.rows.view(np.uint32), a.rows.view(np.uint32))
+    b3.close()
+    a.close()
+    # another decomposition must not pick the directory up
+    with pytest.raises(RuntimeError):
+        ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=4, host_threads=2, checkpoint_dir=str(tmp_path / "b"),
+                                   resume=True)
+
+
+def test_cxx_ensemble_runner_killed_and_resumed(tmp_path):
+    """bin/particlebot_ensemble --checkpoint DIR, SIGKILLed in mid-sweep, then --resume DIR: the gathered rows equal
+    the uninterrupted sweep's bit for bit (world of one rank through the real RCCL calls)."""
+    base = [ENS, EX("example_obstacle.cfg"), "--members", "12", "--sub-batch", "4", "--host-threads", "2", "--set",
+            "nCells", "2500", "--set", "max_time", "240", "--set", "dump_interval", "6"]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29433")
+    r = run(base + ["--out", str(tmp_path / "a.bin")], env=env)
+    assert r.returncode == 0, r.stderr
+    ck = tmp_path / "ck"
+    p = subprocess.Popen(base + ["--checkpoint", str(ck), "--out", str(tmp_path / "b_killed.bin")], env=env,
+                         stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    manifest = ck / "rank0of1" / "sub_000000.manifest"
+    t0 = time.time()
+    while not manifest.exists() and p.poll() is None and time.time() - t0 < 120:
+        time.sleep(0.005)
+    time.sleep(0.3)
+    killed = p.poll() is None
+    p.send_signal(signal.SIGKILL)
+    p.wait()
+    assert manifest.exists()
+    r = run(base + ["--resume", str(ck), "--out", str(tmp_path / "b.bin")], env=env)
+    assert r.returncode == 0, r.stderr
+    a = np.fromfile(tmp_path / "a.bin", np.uint32)
+    b = np.fromfile(tmp_path / "b.bin", np.uint32)
+    assert a.size == b.size and a.size == 12 * 42 * 4 and np.array_equal(a, b), f"killed in mid-run: {killed}"
+    assert '"resumed": true' in r.stdout
