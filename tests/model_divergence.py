@@ -53,11 +53,13 @@ cellS = np.searchsorted(keys, np.arange(G * G + 1))
 gx, gy = cells(spos)                              # lists are looked up with the CURRENT cell
 
 A, FAR, CON, OVH = 33, 17, 31, 3
-tot = dict(p0_trips=0, p0_contact=0, p1_far=0, p1_contact=0, pairs=0, contacts=0, lanes=0)
+tot = dict(p0_trips=0, p0_contact=0, p1_far=0, p1_contact=0, pairs=0, contacts=0, lanes=0, flat_trips=0, flat_contact=0,
+           flat_switch_trips=0)
 rng = np.random.default_rng(0)
 waves = rng.choice(n // 64, size=min(400, n // 64), replace=False)
 for w in waves:
     sl = np.arange(w * 64, w * 64 + 64)
+    flat = [[] for _ in range(64)]   # PF: every lane walks its own five ranges back to back
     for r in range(-2, 3):
         lists = []
         for s in sl:
@@ -67,6 +69,8 @@ for w in waves:
             d = np.hypot(spos[j, 0] - spos[s, 0], spos[j, 1] - spos[s, 1])
             c = (d < srad[j] + srad[s]) & (j != s)
             lists.append(c)
+        for i, c in enumerate(lists):
+            flat[i].append(c)
         L = max(len(c) for c in lists)
         if L == 0:
             continue
@@ -100,6 +104,19 @@ for w in waves:
                 break
         tot["p1_far"] += far
         tot["p1_contact"] += con
+    # PF: the wave runs until its longest lane is done; the contact block runs when any lane's CURRENT candidate is a
+    # contact; a "switch trip" is one in which some lane steps from one range to the next
+    tl = [np.concatenate(f) if f else np.zeros(0, bool) for f in flat]
+    Lf = max(len(c) for c in tl)
+    Mf = np.zeros((64, Lf), bool)
+    Sw = np.zeros((64, Lf), bool)
+    for i, c in enumerate(tl):
+        Mf[i, :len(c)] = c
+        ends = np.cumsum([len(x) for x in flat[i]])[:-1]
+        Sw[i, ends[ends < Lf]] = True
+    tot["flat_trips"] += Lf
+    tot["flat_contact"] += int(Mf.any(axis=0).sum())
+    tot["flat_switch_trips"] += int(Sw.any(axis=0).sum())
     tot["lanes"] += 64
 W = len(waves)
 pairs_per_bot = tot["pairs"] / tot["lanes"]
@@ -111,5 +128,11 @@ print(f"P0: trips per wave {tot['p0_trips'] / W:.1f}, of which with the contact 
 p1 = tot["p1_far"] * (A + FAR + OVH + 4) + tot["p1_contact"] * (CON + 6)
 print(f"P1: far iterations per wave {tot['p1_far'] / W:.1f}, contact iterations {tot['p1_contact'] / W:.1f}; "
       f"modelled VALU per wave {p1 / W:.0f}  ({p1 / p0:.3f} of P0)")
+SWITCH = 5   # range switch through a per-lane queue in LDS: 2 moves, pointer add, 1 select for the look-ahead load
+pf = tot["flat_trips"] * (A + FAR + OVH + 1) + tot["flat_contact"] * CON + tot["flat_switch_trips"] * SWITCH
+print(f"PF (per-lane flattened walk): trips per wave {tot['flat_trips'] / W:.1f} (lane utilisation "
+      f"{tot['pairs'] / 64 / tot['flat_trips']:.3f} against {tot['pairs'] / 64 / tot['p0_trips']:.3f}), with the contact "
+      f"block {tot['flat_contact'] / tot['flat_trips']:.2f}, with a range switch {tot['flat_switch_trips'] / tot['flat_trips']:.2f}; "
+      f"modelled VALU per wave {pf / W:.0f}  ({pf / p0:.3f} of P0)")
 ideal = tot["pairs"] / 64 * (A + OVH) + (tot["pairs"] - tot["contacts"]) / 64 * FAR + tot["contacts"] / 64 * CON
 print(f"divergence-free bound: {ideal / W:.0f} ({ideal / p0:.3f} of P0)")

@@ -31,7 +31,7 @@ cat "$OUT/summary.md"
 if [ "${PB_PROFILE_LARGE:-1}" = "1" ]; then
   OUT=gpurun_out/prof_${TAG}_8m
   mkdir -p "$OUT"
-  ARGS="--bots 8000000 --steps 60 --warmup 20 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg --no-both-sums"
+  ARGS="--bots 8000000 --steps 60 --warmup 20 --prewarm-ms 0 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg --no-both-sums"
   run trace --kernel-trace --stats
   run pmc_fetch --pmc FETCH_SIZE
   run pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
