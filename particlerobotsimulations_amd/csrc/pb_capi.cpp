@@ -425,7 +425,8 @@ bool getv(FILE *fp, T *p, size_t count) { return fread(p, sizeof(T), count, fp) 
 bool readManifest(const std::string &dir, int sub, int &gen, int &nrows, int &finished, long &steps) {
   FILE *f = fopen(manifestPath(dir, sub).c_str(), "r");
   if (!f) return false;
-  const bool ok = fscanf(f, "%d %d %d %ld", &gen, &nrows, &finished, &steps) == 4 && (gen == 0 || gen == 1);
+  const bool ok = fscanf(f, "%d %d %d %ld", &gen, &nrows, &finished, &steps) == 4 && (gen == 0 || gen == 1) &&
+                  nrows >= 0 && nrows <= (1 << 24) && steps >= 0;
   fclose(f);
   return ok;
 }

@@ -13,9 +13,10 @@
 // while the device steps the current one.  --checkpoint DIR saves every member exactly at each summary row
 // (DIR/rank<r>/...); --resume DIR continues a killed sweep from there (same M, N and B), bit-identically.
 //
-// Rendezvous: rank 0 creates the RCCL unique id and serves it over TCP on MASTER_ADDR:MASTER_PORT (default
-// 127.0.0.1:29400) to the other ranks, which retry until it listens -- nothing left behind on disk, nothing a
-// crashed earlier launch could have left either.  --rendezvous FILE exchanges it through that file instead
+// Rendezvous: rank 0 creates the RCCL unique id and serves it over TCP on MASTER_ADDR:(MASTER_PORT + 17) -- not
+// MASTER_PORT itself, which a launcher's own store may hold; $PB_RENDEZVOUS_PORT overrides; default 127.0.0.1:29417 --
+// to the other ranks, which retry until it listens: nothing left behind on disk, nothing a crashed earlier launch
+// could have left either.  --rendezvous FILE exchanges it through that file instead
 // (written to a temporary name and renamed; taken only if rank 0's process, whose id it carries, is alive).
 // A rank that fails still takes part in the collectives: an error flag is reduced first, then all ranks leave.
 #include <arpa/inet.h>
@@ -185,13 +186,14 @@ int main(int argc, char **argv) {
   std::string sweepKey;
   std::vector<std::string> sweepVals;
   int members = 32, subBatch = 0, hostThreads = 0;
-  bool resume = false;
+  bool resume = false, rendezvousTest = false;
   long seed0 = 1000;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--members") && i + 1 < argc) members = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--seed0") && i + 1 < argc) seed0 = atol(argv[++i]);
     else if (!strcmp(argv[i], "--out") && i + 1 < argc) outPath = argv[++i];
     else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc) rendezvous = argv[++i];
+    else if (!strcmp(argv[i], "--rendezvous-test")) rendezvousTest = true;
     else if (!strcmp(argv[i], "--sub-batch") && i + 1 < argc) subBatch = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) hostThreads = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--checkpoint") && i + 1 < argc) ckptDir = argv[++i];
@@ -212,7 +214,7 @@ int main(int argc, char **argv) {
       return 2;
     }
   }
-  if (cfgPath.empty() || members < 1) {
+  if (!rendezvousTest && (cfgPath.empty() || members < 1)) {
     fprintf(stderr, "particlebot_ensemble: a configuration file and --members >= 1 are required\n");
     return 2;
   }
@@ -224,6 +226,29 @@ int main(int argc, char **argv) {
   if (world < 1 || rank < 0 || rank >= world) {
     fprintf(stderr, "particlebot_ensemble: bad rank %d of %d\n", rank, world);
     return 2;
+  }
+  if (rendezvousTest) {
+    // (CPU tests of the id exchange, no GPU involved: rank 0 serves a known 128-byte pattern, the others print what
+    //  they received)
+    const char *addr0 = getenv("MASTER_ADDR");
+    const char *pt = getenv("MASTER_PORT"), *op = getenv("PB_RENDEZVOUS_PORT");
+    const int port0 = op ? atoi(op) : (pt ? atoi(pt) : 29400) + 17;
+    ncclUniqueId fake;
+    unsigned char *fb = (unsigned char *)&fake;
+    for (size_t i = 0; i < sizeof fake; i++) fb[i] = (unsigned char)(i * 7 + 3);
+    bool ok;
+    if (rank == 0) {
+      ok = rendezvous.empty() ? serveId(addr0 ? addr0 : "127.0.0.1", port0, world, fake, 30.0) : publishId(rendezvous, fake);
+      if (ok && !rendezvous.empty()) std::this_thread::sleep_for(std::chrono::milliseconds(1500));  // stay alive for the readers
+    } else {
+      ncclUniqueId got;
+      memset(&got, 0, sizeof got);
+      ok = rendezvous.empty() ? fetchIdTcp(addr0 ? addr0 : "127.0.0.1", port0, rank, &got, 30.0)
+                              : fetchIdFile(rendezvous, &got, 30.0);
+      ok = ok && memcmp(&got, &fake, sizeof fake) == 0;
+    }
+    printf("rendezvous-test rank %d of %d: %s\n", rank, world, ok ? "ok" : "FAILED");
+    return ok ? 0 : 1;
   }
   int ndev = 0;
   CHECK_HIP(hipGetDeviceCount(&ndev));
@@ -237,7 +262,8 @@ int main(int argc, char **argv) {
   ncclUniqueId id;
   const char *addr = getenv("MASTER_ADDR");
   const char *portText = getenv("MASTER_PORT");
-  const int port = portText ? atoi(portText) : 29400;
+  const char *ownPort = getenv("PB_RENDEZVOUS_PORT");
+  const int port = ownPort ? atoi(ownPort) : (portText ? atoi(portText) : 29400) + 17;
   if (rank == 0) {
     CHECK_NCCL(ncclGetUniqueId(&id));
     if (world > 1) {

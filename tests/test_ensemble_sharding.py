@@ -116,3 +116,37 @@ def test_cxx_runner_fails_loudly_without_a_gpu_or_arguments():
         r = subprocess.run([exe, os.path.join(root, "examples", "example_dead_cells.cfg"), "--members", "2"],
                            capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and ("HIP" in r.stderr or "device" in r.stderr), r.stderr
+
+
+@pytest.mark.parametrize("how", ["tcp", "file"])
+def test_cxx_runner_id_exchange_world_size_3(how, tmp_path):
+    """bin/particlebot_ensemble's rendezvous (the RCCL unique id from rank 0 to the other ranks) without any GPU:
+    `--rendezvous-test` runs just that exchange with a known 128-byte pattern.  Three processes, the readers started
+    BEFORE rank 0 (they must retry until it serves), over TCP (the default) and through a file; a stale file left by
+    a dead process must not be taken for this launch's."""
+    import subprocess
+    import sys
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "particlerobotsimulations_amd", "bin",
+                       "particlebot_ensemble")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    extra = []
+    if how == "file":
+        path = tmp_path / "id.bin"
+        # a file from an "earlier launch": right magic, the pid of a process that no longer exists, another id
+        dead = subprocess.Popen([sys.executable, "-c", "pass"])
+        dead.wait()
+        path.write_bytes(b"PBIDF1\0\0" + int(dead.pid).to_bytes(4, "little") + bytes(128))
+        extra = ["--rendezvous", str(path)]
+    env = lambda r: dict(os.environ, RANK=str(r), WORLD_SIZE="3", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                         PB_RENDEZVOUS_PORT=str(port))
+    procs = [subprocess.Popen([exe, "--rendezvous-test"] + extra, env=env(r), stdout=subprocess.PIPE, text=True)
+             for r in (2, 1)]
+    import time
+    time.sleep(0.3)
+    procs.append(subprocess.Popen([exe, "--rendezvous-test"] + extra, env=env(0), stdout=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=60)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert sorted(o.strip() for o in outs) == [f"rendezvous-test rank {r} of 3: ok" for r in range(3)]

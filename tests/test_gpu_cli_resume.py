@@ -162,3 +162,27 @@ def test_cxx_ensemble_runner_killed_and_resumed(tmp_path):
     b = np.fromfile(tmp_path / "b.bin", np.uint32)
     assert a.size == b.size and a.size == 12 * 42 * 4 and np.array_equal(a, b), f"killed in mid-run: {killed}"
     assert '"resumed": true' in r.stdout
+
+
+def test_payload_ensemble_with_xorwow_noise_resumes_exactly(tmp_path):
+    """Object transport (payload mode, phase noise from the cuRAND-shaped XORWOW generator: per-bot generator states
+    that must be rebuilt from seed, bot and draw count on resume) through the pipeline's checkpoints: stopped in
+    mid-run, resumed, same rows and final states as the uninterrupted run."""
+    from helpers import assert_bit_equal
+    from particlerobotsimulations_amd import ensemble
+    cfg = EX("example_object_transport.cfg")
+    members = [f"seed\n{500 + k}" for k in range(6)]
+    common = {"max_time": "40", "dump_interval": "6", "pb_rng": "curand", "phase_update_interval": "4"}
+    a = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=3, host_threads=2, keep_final_states=True)
+    steps = a.run()
+    b = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=3, host_threads=2, checkpoint_dir=str(tmp_path / "ck"))
+    assert b.run(2100) == 2100      # past five phase updates (five draws per bot) and three summary rows
+    b.close()
+    c = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=3, host_threads=2, keep_final_states=True,
+                                   checkpoint_dir=str(tmp_path / "ck"), resume=True)
+    assert c.run() == steps
+    assert np.array_equal(c.rows.view(np.uint32), a.rows.view(np.uint32))
+    for k, (sa, sc) in enumerate(zip(a.final_states(), c.final_states())):
+        for key in ("pos", "vel", "rad"):
+            assert_bit_equal(sc[key], sa[key], f"member {k} {key}")
+    a.close(), c.close()
