@@ -242,7 +242,7 @@ PB_DEV void pbPair(const PbDevParams &P, float ax, float ay, float avx, float av
 //   pbSqrtFast(x)      == sqrtf(x)   for x == 0 or 2^-96 <= x <= FLT_MAX (and +inf)
 //   pbDiv2Fast(a,b,d)  == (a/d, b/d) for normal d with |d| <= 2^126, each numerator either +0 or
 //                                    >= 2^-100 in magnitude, and a normal quotient below 2^96
-// The two quotients share the reciprocal and its Newton step.  pbSelfTestFastMath() (C-ABI
+// The two quotients share the reciprocal and its Newton step; each takes ONE residual correction (see below).  pbSelfTestFastMath() (C-ABI
 // pbSelfTest) checks both claims on the GPU: every float for sqrt, 2^32 sampled triples for div.
 PB_DEV float pbSqrtFast(float x) {
   const float y = __builtin_amdgcn_sqrtf(x);
@@ -259,14 +259,14 @@ PB_DEV void pbDiv2Fast(float a, float b, float d, float &qa, float &qb) {
   float r = __builtin_amdgcn_rcpf(d);
   const float e = __builtin_fmaf(-d, r, 1.0f);
   r = __builtin_fmaf(e, r, r);
+  // ONE residual correction per quotient (round 3).  hipcc's division makes two; with the Newton-refined reciprocal
+  // the second one never changes the result: tools/one_correction_test.hip compares this form with IEEE division on
+  // ALL 2^46 (denominator, numerator) mantissa pairs -- 0 differences (profiles/r3_one_correction_exhaustive.txt) --
+  // and pbSelfTestDivision repeats that through the C-ABI on this very function.
   float q = a * r;
   float t = __builtin_fmaf(-d, q, a);
-  q = __builtin_fmaf(t, r, q);
-  t = __builtin_fmaf(-d, q, a);
   qa = __builtin_fmaf(t, r, q);
   q = b * r;
-  t = __builtin_fmaf(-d, q, b);
-  q = __builtin_fmaf(t, r, q);
   t = __builtin_fmaf(-d, q, b);
   qb = __builtin_fmaf(t, r, q);
 }
@@ -276,7 +276,7 @@ PB_DEV void pbDiv2Fast(float a, float b, float d, float &qa, float &qb) {
 //          land in the reference's contact branch)
 //   dist = two Newton steps on y = d2*s with h = s/2           == sqrtf(d2)
 //   r    = one Newton step on s against dist                   (the reciprocal pbDiv2Fast would refine from v_rcp_f32)
-//   n    = (rx, ry) * r with pbDiv2Fast's two residual corrections == (rx/dist, ry/dist)
+//   n    = (rx, ry) * r with ONE residual correction each           == (rx/dist, ry/dist)
 // tools/rsq_form_test.hip checks this on the GPU EXHAUSTIVELY: the square root for every float that is 0 or in
 // [2^-96, FLT_MAX) (1 879 048 193 values, 0 differ from sqrtf), and the quotient for every d2 in [1, 4) -- all 2^24
 // mantissa x exponent-parity cases -- against every numerator mantissa (2^47 divisions, compared with the
@@ -303,14 +303,12 @@ PB_DEV void pbDistUnitFast(float rx, float ry, float d2, float &dist, float &nx,
     const float c = __builtin_amdgcn_rcpf(y);
     r = __builtin_fmaf(__builtin_fmaf(-y, c, 1.0f), c, c);
   }
+  // one residual correction per component (round 3): exact on all 2^47 (d2, numerator) mantissa pairs, the two
+  // all-ones roots (through the branch above) included -- tools/one_correction_test.hip, pbSelfTestPairGeometry
   float q = rx * r;
   float t = __builtin_fmaf(-y, q, rx);
-  q = __builtin_fmaf(t, r, q);
-  t = __builtin_fmaf(-y, q, rx);
   nx = __builtin_fmaf(t, r, q);
   q = ry * r;
-  t = __builtin_fmaf(-y, q, ry);
-  q = __builtin_fmaf(t, r, q);
   t = __builtin_fmaf(-y, q, ry);
   ny = __builtin_fmaf(t, r, q);
 }

@@ -1,9 +1,14 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/soak
-(timeout 1500 python tests/soak_fuzz.py 300 31 2>&1 | grep -v "^[0-9-]*\.[0-9]* [0-9-]*\.[0-9]* [0-9-]*\.[0-9]* $" | tail -4) > gpurun_out/soak/fuzz_r3.txt 2>&1 &
-F=$!
-(timeout 900 python tests/soak_long_run.py examples/example_obstacle.cfg 360000 60000 2>&1 | grep -v "^[0-9-]*\.[0-9]* [0-9-]*\.[0-9]* [0-9-]*\.[0-9]* $" | tail -3) > gpurun_out/soak/long_obstacle_r3.txt 2>&1
-(timeout 900 python tests/soak_long_run.py examples/example_object_transport.cfg 300000 60000 1 2>&1 | grep -v "^[0-9-]*\.[0-9]* [0-9-]*\.[0-9]* [0-9-]*\.[0-9]* $" | tail -3) > gpurun_out/soak/long_transport_r3.txt 2>&1
-wait $F
-cat gpurun_out/soak/*.txt
-PB_PROFILE_LARGE=1 bash tools/profile.sh r3_v14b > gpurun_out/r3_v14b.log 2>&1; tail -4 gpurun_out/r3_v14b.log
+python - <<'PY'
+import particlerobotsimulations_amd as pb, time
+pb.legacy.cudaInit(0, None)
+t=time.time(); print("pbSelfTest", pb.self_test(1 << 32), round(time.time()-t,1), "s")
+t=time.time(); print("pbSelfTestPairGeometry (all 64 slices: checked, mismatches)", pb.self_test_pair_geometry(0, 64), round(time.time()-t,1), "s")
+t=time.time(); print("pbSelfTestDivision (all 64 slices)", pb.self_test_division(0, 64), round(time.time()-t,1), "s")
+PY
+for rep in 1 2; do
+for lib in lib_base lib; do
+  echo "== $lib"
+  python tools/ab_bench.py --libdir particlerobotsimulations_amd/$lib --variants 2,2s1 --bots 1000000 --rounds 4 --steps 300 --skip 300 2>&1 | tail -2 | cut -c1-130
+done; done
+python -m pytest tests -m gpu -q -x 2>&1 | grep -v "^[0-9-]*\.[0-9]* [0-9-]*\.[0-9]* [0-9-]*\.[0-9]* $" | tail -6
