@@ -274,7 +274,7 @@ PB_DEV void pbDiv2Fast(float a, float b, float d, float &qa, float &qb) {
 // Distance and unit vector of a pair from ONE transcendental (v_rsq_f32) instead of v_sqrt_f32 + v_rcp_f32:
 //   s    = v_rsq_f32(d2), clamped to FLT_MAX (d2 == 0: coincident bots must still get dist = 0, not NaN, to
 //          land in the reference's contact branch)
-//   dist = two Newton steps on y = d2*s with h = s/2           == sqrtf(d2)
+//   dist = ONE Newton step on y = d2*s with h = s/2            == sqrtf(d2)
 //   r    = one Newton step on s against dist                   (the reciprocal pbDiv2Fast would refine from v_rcp_f32)
 //   n    = (rx, ry) * r with ONE residual correction each           == (rx/dist, ry/dist)
 // tools/rsq_form_test.hip checks this on the GPU EXHAUSTIVELY: the square root for every float that is 0 or in
@@ -291,9 +291,10 @@ PB_DEV void pbDistUnitFast(float rx, float ry, float d2, float &dist, float &nx,
   const float s = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(d2), 0.0f, 0x1.fffffep127f);
   const float h = 0.5f * s;
   float y = d2 * s;
-  float e = __builtin_fmaf(-y, y, d2);
-  y = __builtin_fmaf(e, h, y);
-  e = __builtin_fmaf(-y, y, d2);
+  // ONE Newton step (round 3; two until then): exact for every float that is 0 or in [2^-96, FLT_MAX) --
+  // tools/one_newton_root_test.hip, profiles/r3_one_newton_root_exhaustive.txt: 1 879 048 193 values, 0 differ from
+  // sqrtf; pbSelfTest repeats it on this function at the start of every GPU test session
+  const float e = __builtin_fmaf(-y, y, d2);
   y = __builtin_fmaf(e, h, y);
   dist = y;
   const float er = __builtin_fmaf(-y, s, 1.0f);
