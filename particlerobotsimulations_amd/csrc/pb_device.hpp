@@ -552,9 +552,9 @@ struct PbPairXY {
   float tx, ty;
 };
 
-template <bool FAST, class PushRep>
+template <bool FAST, class VelFetch, class PushRep>
 PB_DEV PbPairXY pbPairEvalXY(const PbContactK &P, bool live, float ax, float ay, float avx, float avy, float ra,
-                             float bx, float by, float rb, float vbx, float vby, float attraction, float slope,
+                             float bx, float by, float rb, VelFetch velB, float attraction, float slope,
                              PushRep pushRep) {
   const float near1 = 0.0009f, near2 = 0.0019f, fmin_attr = 2.5f;
   const float rx = bx - ax, ry = by - ay;
@@ -591,7 +591,8 @@ PB_DEV PbPairXY pbPairEvalXY(const PbContactK &P, bool live, float ax, float ay,
     }
     if ((mNear & mContact) != 0ull) {
       // (lanes out of contact compute on their neighbour's velocity too; their result is not selected)
-      const float rvx = vbx - avx, rvy = vby - avy;
+      const float2 vb = velB();
+      const float rvx = vb.x - avx, rvy = vb.y - avy;
       const float vn = pbDot(rvx, rvy, nx, ny);
       const float tvx = rvx - vn * nx, tvy = rvy - vn * ny;
       const float ks = -P.spring * (reach - dist);

@@ -30,6 +30,9 @@
 // (64 VGPRs, 28 spilled), 120.8 at 7 (72), 119.8 at 6 (80), 121.4 at 5 (81, no bound) against 114.0
 // for NB = 1 (63 VGPRs, 8 waves/SIMD): waves, not ILP inside a wave, are what fills the VALU pipe.
 
+#ifndef PB_LAZY_VEL
+#define PB_LAZY_VEL 1  // (0: the round-2 form, the neighbour's velocity prefetched with every posrad)
+#endif
 #ifndef PB_SWEEP_EXPERIMENT
 #define PB_SWEEP_EXPERIMENT 0
 #endif
@@ -241,7 +244,7 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
           // dead-sum form: no Sum|F_attr|; a contact's magnitude and the Sum|F_rep| chain only in the
           // trips in which some lane of the wave is in contact
           const PbPairXY t = pbPairEvalXY<FAST>(
-              CK, live[0], me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, w.x, w.y, A[0], K[0], [&](bool mine, float m2) {
+              CK, live[0], me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, [&]() { return w; }, A[0], K[0], [&](bool mine, float m2) {
                 float mag;
                 if (FAST) {
                   mag = pbSqrtFast(m2);
@@ -311,17 +314,17 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
     };
 #endif
     const OffT selfOff16 = selfOff + 16u;
-    auto one = [&](const float4 &q, const float2 &vq, bool isLive) __attribute__((always_inline)) {
+    auto one = [&](const float4 &q, auto velOf, bool isLive) __attribute__((always_inline)) {
       const bool live[1] = {isLive};
       const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
       const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
       const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
       if (ASUM) {
         PbPairTerm t[1];
-        pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K, [&](int) { return vq; }, t);
+        pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K, [&](int) { return velOf(); }, t);
         pbPairAdd(live[0], t[0], F);
       } else {
-        const PbPairXY t = pbPairEvalXY<FAST>(CK, live[0], me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, vq.x, vq.y, A[0],
+        const PbPairXY t = pbPairEvalXY<FAST>(CK, live[0], me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, velOf, A[0],
                                               K[0], [&](bool mine, float m2) { rep.push(mine, m2, F.fr); });
         if (live[0]) {
           // (a real exec-masked block -- two scalar instructions -- instead of two selects per trip)
@@ -363,23 +366,20 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
       bounds(si + 2 * stride, loB, hiB);   // bounds of the one after
       if (lo < end) {
 #if PB_PREFETCH_DEPTH == 2
-        // look-ahead of TWO neighbours (three register sets rotating through a loop unrolled by three)
+        // look-ahead of TWO neighbours (three register sets rotating through a loop unrolled by three); velocities
+        // fetched inside the contact block
         OffT off = lo, hoff = lo >> 1;
         const OffT endm16 = end - 16u, endm32 = end > 32u ? end - 32u : 0u, endm48 = end > 48u ? end - 48u : 0u;
         float4 q1 = atI(off, 16);
-        float2 v1 = vatI(hoff, 8);
         for (;;) {
           const float4 q2 = atI(off, 32);
-          const float2 v2 = vatI(hoff, 16);
-          one(q0, v0, off != selfOff);
+          one(q0, [&]() { return vatI(hoff, 0); }, off != selfOff);
           if (off >= endm16) break;
           q0 = atI(off, 48);
-          v0 = vatI(hoff, 24);
-          one(q1, v1, off != selfOff - 16u);
+          one(q1, [&]() { return vatI(hoff, 8); }, off != selfOff - 16u);
           if (off >= endm32) break;
           q1 = atI(off, 64);
-          v1 = vatI(hoff, 32);
-          one(q2, v2, off != selfOff - 32u);
+          one(q2, [&]() { return vatI(hoff, 16); }, off != selfOff - 32u);
           if (off >= endm48) break;
           off += 48u;
           hoff += 24u;
@@ -389,18 +389,34 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
         // offset of its velocity
         OffT off = lo, hoff = lo >> 1;
         const OffT endm = end - 16u;
+#if PB_LAZY_VEL
+        // experiment: the neighbour's velocity fetched inside the contact block (22 % of the trips on the bench
+        // lattice) instead of with every posrad: one vector-memory instruction per trip instead of two
+        (void)v0;
+        for (;;) {
+          const float4 q1 = atI(off, 16);
+          one(q0, [&]() { return vatI(hoff, 0); }, off != selfOff);
+          if (off >= endm) break;
+          off += 32u;
+          hoff += 16u;
+          q0 = atI(off, 0);
+          one(q1, [&]() { return vatI(hoff, -8); }, off != selfOff16);
+          if (off >= end) break;
+        }
+#else
         for (;;) {
           const float4 q1 = atI(off, 16);
           const float2 v1 = vatI(hoff, 8);
-          one(q0, v0, off != selfOff);
+          one(q0, [&]() { return v0; }, off != selfOff);
           if (off >= endm) break;
           off += 32u;
           hoff += 16u;
           q0 = atI(off, 0);
           v0 = vatI(hoff, 0);
-          one(q1, v1, off != selfOff16);
+          one(q1, [&]() { return v1; }, off != selfOff16);
           if (off >= end) break;
         }
+#endif
 #endif
       }
     }

@@ -1,13 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import particlerobotsimulations_amd as pb, time
-pb.legacy.cudaInit(0, None)
-t=time.time(); print("pbSelfTest", pb.self_test(1 << 32), round(time.time()-t,1), "s")
-t=time.time(); print("pbSelfTestPairGeometry (all 64 slices: checked, mismatches)", pb.self_test_pair_geometry(0, 64), round(time.time()-t,1), "s")
-PY
 for rep in 1 2; do
-for lib in lib_base lib; do
+for lib in lib lib_p2; do
   echo "== $lib"
-  python tools/ab_bench.py --libdir particlerobotsimulations_amd/$lib --variants 2,2s1 --bots 1000000 --rounds 4 --steps 300 --skip 300 2>&1 | tail -2 | cut -c1-130
+  python tools/ab_bench.py --libdir particlerobotsimulations_amd/$lib --variants 2,1 --bots 1000000 --rounds 4 --steps 300 --skip 300 2>&1 | tail -2 | cut -c1-250
 done; done
 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "^[0-9-]*\.[0-9]* [0-9-]*\.[0-9]* [0-9-]*\.[0-9]* $" | tail -4
