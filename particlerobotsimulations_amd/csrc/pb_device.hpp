@@ -34,6 +34,12 @@ struct PbDevParams {
   float x1obs[PB_MAX_OBSTACLES], x2obs[PB_MAX_OBSTACLES], y1obs[PB_MAX_OBSTACLES], y2obs[PB_MAX_OBSTACLES];
   int32_t n_cir;
   float xc[PB_MAX_OBSTACLES], yc[PB_MAX_OBSTACLES], rc[PB_MAX_OBSTACLES];
+  // derived on the host (pbFlattenParams), in the reference's fp32 operation order: values that every bot would
+  // otherwise work out for itself with an IEEE division per step although they only depend on the parameters
+  uint32_t gridXLog2;     // gridX is a power of two (engine: checked by pbSimCreateBatch): row * gridX as a shift
+  float actUpSlope;       // (max_radius - min_radius) / rise_period      (impl.cuh:145)
+  float actDownSlope;     // (min_radius - max_radius) / rise_period      (impl.cuh:147)
+  float actGain;          // max_speed * max_radius / constraint          (impl.cuh:162), max_speed = 0.1f
 };
 
 static inline void pbFlattenParams(PbDevParams &d, const SimParams &p, float wallHalf) {
@@ -72,6 +78,18 @@ static inline void pbFlattenParams(PbDevParams &d, const SimParams &p, float wal
   d.nobstacles = p.nobstacles < 0 ? 0 : (p.nobstacles > PB_MAX_OBSTACLES ? PB_MAX_OBSTACLES : p.nobstacles);
   d.n_cir = p.n_cir_obstacles < 0 ? 0
                                   : (p.n_cir_obstacles > PB_MAX_OBSTACLES ? PB_MAX_OBSTACLES : p.n_cir_obstacles);
+  d.gridXLog2 = 0;
+  while ((1u << d.gridXLog2) < d.gridX && d.gridXLog2 < 31u) d.gridXLog2++;
+  {
+    // (volatile: keep the compiler from folding these into anything but the plain fp32 operations of the reference)
+    volatile float up = (p.max_radius - p.min_radius) / p.rise_period;
+    volatile float down = (p.min_radius - p.max_radius) / p.rise_period;
+    const float max_speed = 0.1f;
+    volatile float gain = max_speed * p.max_radius / p.constraint;
+    d.actUpSlope = up;
+    d.actDownSlope = down;
+    d.actGain = gain;
+  }
   for (int i = 0; i < PB_MAX_OBSTACLES; i++) {
     const bool r = i < d.nobstacles;
     d.x1obs[i] = (r && p.x1obs) ? p.x1obs[i] : 0.0f;
@@ -158,17 +176,18 @@ PB_DEV float pbActuate(const PbDevParams &P, float rad, float phase, int dead, f
   if (t1 >= period) t1 = t1 - period * floorf(t1 / period);
   if (t1 >= 2 * P.rise_period) return rad;
   float target;
+  // (the two slopes and the gain below only depend on the parameters: divided once, on the host, pbFlattenParams)
   if (t1 <= P.rise_period)
-    target = P.min_radius + (P.max_radius - P.min_radius) / P.rise_period * t1;
+    target = P.min_radius + P.actUpSlope * t1;
   else
-    target = P.max_radius + (P.min_radius - P.max_radius) / P.rise_period * (t1 - P.rise_period);
+    target = P.max_radius + P.actDownSlope * (t1 - P.rise_period);
   const float want = target - rad;
   float dr = 0;
   const float max_speed = 0.1f;
   float torque = want * P.constraint * rad / max_speed / P.max_radius / dt;
   torque = fminf(torque, P.constraint);
   if (want > 0) {
-    if (torque / rad > absR) dr = max_speed * P.max_radius / P.constraint * (torque / rad - absR) * dt;
+    if (torque / rad > absR) dr = P.actGain * (torque / rad - absR) * dt;
   } else {
     if (P.constrained_contraction) {
       if (-P.constraint_contraction * want > absA * rad)

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
     auto bounds = [&](int si, uint32_t &lo, uint32_t &hi) __attribute__((always_inline)) {
       lo = hi = selfOff;
       if (si < 10) {
-        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) << P.gridXLog2;
         lo = cellS[row + ((si & 1) ? 0u : mx0)] * 16u;
         hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)] * 16u;
       }

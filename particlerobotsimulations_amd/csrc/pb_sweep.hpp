@@ -195,7 +195,7 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
 #pragma unroll
       for (int si = 0; si < 10; si++) {
         const int sg = si & 1;
-        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) << P.gridXLog2;
         uint32_t lo = 0, hi = 0;
         if (sg < nseg) {
           lo = cellS[row + (sg == 0 ? mx0 : 0u)] - base;
@@ -339,7 +339,7 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
     auto bounds = [&](int si, OffT &lo, OffT &hi) __attribute__((always_inline)) {
       lo = hi = selfOff;
       if (si < 10) {
-        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) << P.gridXLog2;
         lo = (OffT)(cellS[row + ((si & 1) ? 0u : mx0)] - base) * 16u;
         hi = (OffT)(cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base) * 16u;
       }
@@ -451,7 +451,7 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
     auto bounds = [&](int si, uint32_t &lo, uint32_t &hi) __attribute__((always_inline)) {
       lo = hi = selfOff;
       if (si < 10) {
-        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+        const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) << P.gridXLog2;
         lo = (cellS[row + ((si & 1) ? 0u : mx0)] - base) * 16u;
         hi = (cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base) * 16u;
       }
@@ -494,7 +494,7 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
 #pragma unroll 1
   for (int si = 0; si < 10; si++) {
     if ((si & 1) && nseg == 1) continue;  // second range of a row only exists at the x-wrap
-    const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) * GX;
+    const uint32_t row = ((uint32_t)(gy + (si >> 1) - 2) & (P.gridY - 1u)) << P.gridXLog2;
     const uint32_t lo = cellS[row + ((si & 1) ? 0u : mx0)] - base;
     const uint32_t hi = cellS[row + ((si & 1) ? 5u - first : mx0 + first)] - base;
     if (FLAT) {
