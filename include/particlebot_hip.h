@@ -146,6 +146,14 @@ typedef struct pbSimStats {
 
 const char *pbGetLastErrorString(void);
 
+/* The calling THREAD's current HIP device.  A batch lives on the device that was current when it was created
+ * (pbSimCreate*), and HIP's current device is per host thread -- a new thread starts on device 0 -- so a program that
+ * creates batches from worker threads (one process per GPU, LOCAL_RANK > 0) sets the device in each of them first.
+ * (Every other pbSim* call switches to its batch's device by itself.)  The ensemble pipeline does this for the thread
+ * that calls pbEnsemblePipelineRun. */
+int pbGetDevice(int *device);
+int pbSetDevice(int device);
+
 /* Creates a simulation of params->nCells bots on the current device.  The parameter block is
  * copied (obstacle arrays included, at most PB_MAX_OBSTACLES each).  wallHalf <= 0 selects the
  * reference's 64.  gridSize must be a power of two >= 8 in each dimension.  State starts zeroed

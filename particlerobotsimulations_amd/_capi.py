@@ -115,6 +115,8 @@ SYMBOLS = {
     "calcCOG": (None, [_VP, _VP, _VP, _I, _F, _I, _F]),
     "sortParticlebots": (None, [_VP, _VP, _U]),
     "pbGetLastErrorString": (C.c_char_p, []),
+    "pbGetDevice": (_I, [C.POINTER(_I)]),
+    "pbSetDevice": (_I, [_I]),
     "pbSimCreate": (_I, [C.POINTER(_VP), C.POINTER(SimParams), _F]),
     "pbSimDestroy": (None, [_VP]),
     "pbSimCreateBatch": (_I, [C.POINTER(_VP), C.POINTER(SimParams), _I, _F]),

@@ -674,6 +674,7 @@ struct Pipeline {
   unsigned nbots = 0;
   pbEnsembleTimings tm{};
   std::vector<double> cpuSeconds;  // per producer thread
+  int device = -1;      // the creating thread's HIP device: Run may be called from another thread (which starts on 0)
   std::string ckptDir;  // checkpoints (pbEnsemblePipelineSetCheckpoint); empty: none
   bool resume = false;
   bool started = false;
@@ -827,6 +828,7 @@ void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *com
   }
   p->tm.host_threads = p->threads;
   p->tm.sub_batch = p->sub;
+  if (pbGetDevice(&p->device) != PB_OK) p->device = -1;  // (no device: the dry-run consumer of the CPU tests)
   if (checkpoint_dir && checkpoint_dir[0]) {
     p->ckptDir = checkpoint_dir;
     p->resume = resume != 0;
@@ -872,6 +874,7 @@ void pbEnsemblePipelineDestroy(void *pv) { delete (Pipeline *)pv; }
 long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, int *rows, pbEnsembleTimings *timings) {
   Pipeline *p = (Pipeline *)pv;
   if (!p || p->consumedUpTo != 0) return -1;  // one run per pipeline
+  if (p->device >= 0 && pbSetDevice(p->device) != PB_OK) return -1;  // this thread may be new: batches go where Create was
   const double t0 = nowSeconds();
   long steps = 0;
   int nrowsAll = 0;

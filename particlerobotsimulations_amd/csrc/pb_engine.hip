@@ -1067,6 +1067,17 @@ int pbSimGetConfig(pbSim *S, pbSimConfig *cfg) {
   return PB_OK;
 }
 
+int pbGetDevice(int *device) {
+  if (!device) return PB_ERR_ARG;
+  PB_TRY(hipGetDevice(device));
+  return PB_OK;
+}
+
+int pbSetDevice(int device) {
+  PB_TRY(hipSetDevice(device));
+  return PB_OK;
+}
+
 int pbSimSetMinDistanceMode(pbSim *S, int mode) {
   if (!S || mode < 0 || mode > 1) return PB_ERR_ARG;
   S->minDistanceMode = mode;
