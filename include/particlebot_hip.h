@@ -235,6 +235,12 @@ int pbSimSetResortEveryStep(pbSim *sim, int on);
 int pbSimSetMinDistanceMode(pbSim *sim, int mode);
 int pbSetMinDistanceMode(int mode);
 
+/* The smallest non-negative float x with sqrtf(x) >= c (0 when c <= 0 or NaN): `length(v) < c` of the static-friction
+ * hold (particlebot_impl.cuh:809-811) is decided as `dot(v,v) < pbHostSqrtThreshold(c)`, the same decision for every
+ * input because sqrtf is correctly rounded and therefore monotone.  Host-only (no GPU needed); exported for
+ * tests/test_sqrt_threshold.py. */
+float pbHostSqrtThreshold(float c);
+
 /* Force-kernel variant of a simulation: 0 reference-shaped branches, 1 branch-free, 2 branch-free
  * with the fast exact sqrt/division forms (default; falls back to 1 when the simulation's
  * constants are outside their proven domain).  Variants 0-2 give bit-identical results.

@@ -142,6 +142,7 @@ SYMBOLS = {
     "pbSimSetResortEveryStep": (_I, [_VP, _I]),
     "pbSimSetMinDistanceMode": (_I, [_VP, _I]),
     "pbSetMinDistanceMode": (_I, [_I]),
+    "pbHostSqrtThreshold": (C.c_float, [C.c_float]),
     "pbSimSetForceVariant": (_I, [_VP, _I]),
     "pbSimSetLanesPerBot": (_I, [_VP, _I]),
     "pbSimSetResident": (_I, [_VP, _I]),

@@ -10,6 +10,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
+#include <math.h>
 
 #include "particlebot_kernel.h"
 
@@ -40,7 +42,31 @@ struct PbDevParams {
   float actUpSlope;       // (max_radius - min_radius) / rise_period      (impl.cuh:145)
   float actDownSlope;     // (min_radius - max_radius) / rise_period      (impl.cuh:147)
   float actGain;          // max_speed * max_radius / constraint          (impl.cuh:162), max_speed = 0.1f
+  // static-friction hold (impl.cuh:809-811): length(v) < 0.000001f && length(F) < 2 mu g.  sqrtf is correctly rounded,
+  // hence monotone: sqrtf(x) < c  <=>  x < T(c), T(c) = the smallest float whose root is >= c (found on the host by
+  // bisection over the float bit patterns with the same correctly rounded sqrtf): two compares of the squared lengths
+  // instead of two IEEE square roots per bot per step, same decisions for every input (NaN included: both false)
+  float holdV2;           // T(0.000001f)
+  float holdF2, holdF2Payload;  // T(2 friction gravity), and with the payload's frictionFactor / massFactor
 };
+
+// smallest non-negative float x with sqrtf(x) >= c (+inf if there is none among the finite ones, 0 if c <= 0 or NaN:
+// then `sqrtf(x) < c` is never true, and neither is `x < 0`)
+static inline float pbSqrtThreshold(float c) {
+  if (!(c > 0.0f)) return 0.0f;
+  uint32_t lo = 0u, hi = 0x7F800000u;  // bit patterns of +0 .. +inf: sqrtf is monotone over them
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2u;
+    float x;
+    memcpy(&x, &mid, 4);
+    volatile float r = sqrtf(x);
+    if (r >= c) hi = mid;
+    else lo = mid + 1u;
+  }
+  float x;
+  memcpy(&x, &lo, 4);
+  return x;
+}
 
 static inline void pbFlattenParams(PbDevParams &d, const SimParams &p, float wallHalf) {
   d.gridX = p.gridSize.x;
@@ -89,6 +115,12 @@ static inline void pbFlattenParams(PbDevParams &d, const SimParams &p, float wal
     d.actUpSlope = up;
     d.actDownSlope = down;
     d.actGain = gain;
+    d.holdV2 = pbSqrtThreshold(0.000001f);
+    volatile float hold = 2.0f * p.friction * p.gravity;
+    volatile float fp = p.friction * p.frictionFactor, gp = p.gravity * p.massFactor;  // pbFrictionAndKick's order
+    volatile float holdP = 2.0f * fp * gp;
+    d.holdF2 = pbSqrtThreshold(hold);
+    d.holdF2Payload = pbSqrtThreshold(holdP);
   }
   for (int i = 0; i < PB_MAX_OBSTACLES; i++) {
     const bool r = i < d.nobstacles;
@@ -822,7 +854,8 @@ PB_DEV void pbFrictionAndKick(const PbDevParams &P, bool payload, float fx, floa
     friction *= P.frictionFactor;
     gravity *= P.massFactor;
   }
-  if (pbLen(vx, vy) < 0.000001f && pbLen(fx, fy) < (2.0f * friction * gravity)) {
+  // length(v) < 0.000001f && length(F) < 2 friction gravity, on the squared lengths (PbDevParams::holdV2 / holdF2)
+  if (pbDot(vx, vy, vx, vy) < P.holdV2 && pbDot(fx, fy, fx, fy) < (payload ? P.holdF2Payload : P.holdF2)) {
     fx = 0.0f;
     fy = 0.0f;
   }

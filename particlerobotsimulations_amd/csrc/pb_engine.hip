@@ -1090,6 +1090,8 @@ int pbSetMinDistanceMode(int mode) {
   return PB_OK;
 }
 
+float pbHostSqrtThreshold(float c) { return pbSqrtThreshold(c); }
+
 int pbSimSetResortEveryStep(pbSim *S, int on) {
   if (!S) return PB_ERR_ARG;
   S->resortEveryStep = on != 0;

@@ -43,6 +43,17 @@ def timed(ens, steps):
     return (time.perf_counter() - t0) / steps * 1e6
 
 
+if os.environ.get("PB_ENS_SPLIT"):
+    # the same 32 + 32 members as FOUR batches of 16 on four streams (four host threads)
+    k = int(os.environ["PB_ENS_SPLIT"])
+    mk2 = lambda cfg, lo, hi: ensemble.LocalEnsemble(EX(cfg), [f"seed\n{1000 + j}" for j in range(lo, hi)], common)
+    per = args.members // k
+    parts = [mk2(c, i * per, (i + 1) * per) for c in ("example_obstacle.cfg", "example_object_transport.cfg") for i in range(k)]
+    for e in parts:
+        e.run_steps(args.skip)
+    for rep in range(2):
+        print(f"{2 * k} batches of {per} members on {2 * k} streams: {timed(parts, args.steps):.2f} us per step of all {2 * args.members} members")
+    sys.exit(0)
 a, b = mk("example_obstacle.cfg"), mk("example_object_transport.cfg")
 for e in (a, b):
     e.run_steps(args.skip)
