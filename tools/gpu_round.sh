@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( time timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 ) 2>&1
-timeout 600 python bench.py > gpurun_out/arena_default.json 2> gpurun_out/arena_default.err; tail -c 600 gpurun_out/arena_default.json
-PB_HOST_THREADS=32 timeout 1200 python bench.py --workload ensemble5 --members-per-gpu 1024 --steps 20 --warmup 5 > gpurun_out/r3_cfg5_full_pipeline.json 2> gpurun_out/r3_cfg5_full_pipeline.err; tail -c 1500 gpurun_out/r3_cfg5_full_pipeline.json
+for d in 14 10 12; do echo "--- 7 waves debug $d"; PB_PIPE_WAVES=7 PB_PIPE_DEBUG=$d timeout 300 python tools/pipelined_ab.py 1000000 400 --time-only 2>&1 | tail -3 | cut -c1-330; done
