@@ -1,3 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for d in 14 10 12; do echo "--- 7 waves debug $d"; PB_PIPE_WAVES=7 PB_PIPE_DEBUG=$d timeout 300 python tools/pipelined_ab.py 1000000 400 --time-only 2>&1 | tail -3 | cut -c1-330; done
+timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -3
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+bash tools/profile.sh r3_v16 > gpurun_out/profile_r3_v16.log 2>&1; tail -5 gpurun_out/profile_r3_v16.log
+timeout 600 python bench.py > gpurun_out/arena_default.json 2> gpurun_out/arena_default.err; tail -c 300 gpurun_out/arena_default.json
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/arena_steps20.json 2> gpurun_out/arena_steps20.err; tail -c 300 gpurun_out/arena_steps20.json
