@@ -469,7 +469,11 @@ ENSEMBLE_WORKLOADS = {
 
 FULL_RUN = {   # the BASELINE configuration at full length: max_time, timesteps per member, sub-batch
     "ensemble4": {"max_time": "1200", "steps": 120000, "sub_batch": 0},    # 100 actuation cycles; members of 500 / 201 bots
-    "ensemble5": {"max_time": "120", "steps": 12000, "sub_batch": 8},      # 10 cycles; 10^5-bot members, placement 1.4 s each
+    # 10 cycles; 10^5-bot members, placement 0.85-1.6 s each.  -1: one placement round of the producer pool per sub-batch
+    # (31 members with PB_HOST_THREADS=32).  Round 3 measured, whole config on one GPU: 8 members per sub-batch 104.1 s
+    # (66 us per step of 8 x 10^5 bots carries the full ramp and drain), 32 members 95.4 s (first sub-batch ready
+    # after TWO placement rounds: 3.0 s of waiting), 64 members 28.0 s per quarter against 26.0 s with 32.
+    "ensemble5": {"max_time": "120", "steps": 12000, "sub_batch": -1},
 }
 
 
@@ -782,6 +786,8 @@ def main():
                     help="bound the timesteps per member of the ensemble end-to-end run (default: the configuration's "
                          "full length, 120000 for ensemble4 and 12000 for ensemble5)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the ensemble end-to-end run")
+    ap.add_argument("--sub-batch", type=int, default=None,
+                    help="members per sub-batch of the end-to-end pipeline (default: FULL_RUN's value for the workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-survey-literal", action="store_true")
     ap.add_argument("--no-streamlined", action="store_true")
@@ -800,6 +806,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path")
     args = ap.parse_args()
+    if args.sub_batch is not None and args.workload in FULL_RUN:
+        FULL_RUN[args.workload]["sub_batch"] = args.sub_batch
     if args.members_per_gpu is None:
         args.members_per_gpu = 32 if args.workload == "ensemble4" else 8
 

@@ -62,6 +62,16 @@ def test_look_ahead_is_bounded():
         assert ahead >= sub          # ... and they do run ahead while the consumer dwells
 
 
+def test_automatic_sub_batch_is_one_placement_round():
+    """sub_batch -1: as many members per sub-batch as there are producer threads (every sub-batch is ready after ONE
+    round of the pool); same members, and the look-ahead bound follows that size."""
+    ref, _ = _dry(0, 1)
+    for threads in (1, 3, 5):
+        sums, ahead = _dry(-1, threads, dwell=3)
+        assert np.array_equal(sums, ref), threads
+        assert ahead <= 3 * threads, (threads, ahead)
+
+
 def test_bad_cfg_fails_cleanly():
     from particlerobotsimulations_amd.ensemble import PipelinedEnsemble
     p = PipelinedEnsemble(os.path.join(ROOT, "examples", "no_such.cfg"), _members(3), None, sub_batch=2, host_threads=2)

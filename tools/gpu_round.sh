@@ -1,7 +1,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -3
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-bash tools/profile.sh r3_v16 > gpurun_out/profile_r3_v16.log 2>&1; tail -5 gpurun_out/profile_r3_v16.log
-timeout 600 python bench.py > gpurun_out/arena_default.json 2> gpurun_out/arena_default.err; tail -c 300 gpurun_out/arena_default.json
-timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/arena_steps20.json 2> gpurun_out/arena_steps20.err; tail -c 300 gpurun_out/arena_steps20.json
+timeout 600 python -m pytest tests/test_gpu_ensemble_pipeline.py tests/test_gpu_bench_contract.py -x -q 2>&1 | tail -3
+PB_HOST_THREADS=32 timeout 900 python bench.py --workload ensemble5 --members-per-gpu 256 --steps 20 --warmup 5 > gpurun_out/r3_cfg5_quarter_pipeline_auto.json 2> gpurun_out/r3_cfg5_quarter_pipeline_auto.err
+PB_HOST_THREADS=32 timeout 1200 python bench.py --workload ensemble5 --members-per-gpu 1024 --steps 20 --warmup 5 > gpurun_out/r3_cfg5_full_pipeline_auto.json 2> gpurun_out/r3_cfg5_full_pipeline_auto.err
+python - <<PY
+import json
+for f in ('quarter','full'):
+    d=json.load(open(f'gpurun_out/r3_cfg5_{f}_pipeline_auto.json'))
+    e=d['end_to_end']; print(f, 'wall', e['wall_s'], e['value_end_to_end'], e['pipeline_rank0'], e['last_rows_time_comx_comy_dist'][0][:2])
+PY
