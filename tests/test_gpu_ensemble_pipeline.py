@@ -23,13 +23,16 @@ def test_rows_and_states_do_not_depend_on_the_split(orc, cfg, over):
     members = [f"seed\n{s}" for s in seeds]
     ref_rows, ref_steps, ref_states = ensemble.run_local(EX(cfg), members, common, final_state=True)
     assert ref_rows.shape[:2] == (16, 4) and ref_steps in (1260, 1261)
-    for sub, threads in ((8, 3), (5, 1), (32, 4), (0, 2)):   # even split, ragged split, one batch (two spellings)
+    # even split, ragged split, one batch (two spellings), automatic (-1: one placement round = 3 members per sub-batch)
+    for sub, threads in ((8, 3), (5, 1), (32, 4), (0, 2), (-1, 3)):
         p = ensemble.PipelinedEnsemble(EX(cfg), members, common, sub_batch=sub, host_threads=threads,
                                        keep_final_states=True)
         steps = p.run()
         tm = p.timings
         assert steps == ref_steps
-        assert tm["sub_batches"] == (-(-16 // sub) if 0 < sub < 16 else 1) and tm["host_threads"] == threads
+        used = threads if sub == -1 else sub
+        assert tm["sub_batches"] == (-(-16 // used) if 0 < used < 16 else 1) and tm["host_threads"] == threads
+        assert tm["sub_batch"] == (used if 0 < used < 16 else 16)
         assert tm["wall_s"] > 0 and tm["device_s"] > 0 and tm["placement_cpu_s"] > 0
         rows, states = p.rows, p.final_states()
         p.close()
