@@ -1,7 +1,9 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-run() { python bench.py --workload ensemble4 --members-per-gpu $1 --steps 2400 --warmup 20 --no-end-to-end --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('members/cfg', $1, 'us per batched step', d['ms_per_step']*1e3, 'long', d.get('ms_per_step_long',0)*1e3)"; }
-echo "--- default build"; run 256; run 128; run 512
-touch particlerobotsimulations_amd/csrc/pb_resident.hip
-make -C particlerobotsimulations_amd/csrc EXTRA_DEVFLAGS=-DPB_RESIDENT_MIN_WAVES=8 all 2>&1 | grep -E "error|warning" | head -3
-echo "--- 64 VGPRs (two workgroups per CU)"; run 256; run 128; run 512
+mkdir -p gpurun_out/soaks
+timeout 300 python -m pytest tests/test_gpu_ensemble_pipeline.py -x -q 2>&1 | tail -2
+( timeout 2400 python tests/soak_fuzz.py 300 53 > gpurun_out/soaks/fuzz_r3_v16.txt 2>&1; tail -2 gpurun_out/soaks/fuzz_r3_v16.txt ) &
+timeout 900 python tests/soak_long_run.py examples/example.cfg 720000 120000 0 > gpurun_out/soaks/long_example_r3_v16.txt 2>&1; tail -1 gpurun_out/soaks/long_example_r3_v16.txt
+timeout 900 python tests/soak_long_run.py examples/example_object_transport.cfg 300000 60000 1 > gpurun_out/soaks/long_transport_r3_v16.txt 2>&1; tail -1 gpurun_out/soaks/long_transport_r3_v16.txt
+timeout 900 python tests/soak_long_run.py examples/example_obstacle.cfg 240000 60000 2 > gpurun_out/soaks/long_obstacle_r3_v16.txt 2>&1; tail -1 gpurun_out/soaks/long_obstacle_r3_v16.txt
+timeout 900 python tests/soak_bench_parity.py > gpurun_out/soaks/bench_parity_r3_v16.txt 2>&1; tail -1 gpurun_out/soaks/bench_parity_r3_v16.txt
+wait
