@@ -345,6 +345,9 @@ int pbSelfTest(unsigned long long div_samples, unsigned long long *sqrt_checked,
  * against every numerator mantissa (2^23): the root against sqrtf and both quotients against IEEE division.
  * `checked` counts (d2, numerator) pairs (2^41 per slice, ~1.5 s of one MI355X); all 64 slices are the proof
  * DESIGN.md section 4 quotes (2^47 pairs, 0 mismatches). */
+/* The static-friction hold's squared-length threshold for the constant c (pbHostSqrtThreshold) against the device's
+ * IEEE sqrtf: `sqrtf(x) < c` and `x < T(c)` compared for EVERY non-negative float bit pattern x (2^31, NaNs included). */
+int pbSelfTestHoldThreshold(float c, unsigned long long *checked, unsigned long long *mismatches);
 int pbSelfTestPairGeometry(unsigned first_slice, unsigned slices, unsigned long long *checked,
                            unsigned long long *mismatches);
 /* The same for pbDiv2Fast (the division of the attraction term by gap^2): every denominator mantissa of

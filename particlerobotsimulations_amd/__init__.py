@@ -25,6 +25,13 @@ def self_test(div_samples=1 << 32):
     return {k: int(v.value) for k, v in zip(keys, vals)}
 
 
+def self_test_hold_threshold(c):
+    """pbSelfTestHoldThreshold: `sqrtf(x) < c` against `x < T(c)` on the GPU for every non-negative float x."""
+    checked, bad = C.c_ulonglong(), C.c_ulonglong()
+    _capi.check(_capi.lib().pbSelfTestHoldThreshold(float(c), C.byref(checked), C.byref(bad)), "pbSelfTestHoldThreshold")
+    return {"checked": checked.value, "mismatches": bad.value}
+
+
 def self_test_pair_geometry(first_slice=0, slices=64):
     """pbSelfTestPairGeometry: pbDistUnitFast against sqrtf and IEEE division on EVERY (d2, numerator)
     mantissa pair of `slices` of the 64 slices of d2 in [1, 4) (all 64: 2^47 pairs, ~90 s of one MI355X)."""

@@ -158,6 +158,7 @@ SYMBOLS = {
     "pbClockSampleBegin": (_I, [C.POINTER(_VP), C.c_double]),
     "pbClockSampleEnd": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pbSelfTest": (_I, [C.c_ulonglong] + [C.POINTER(C.c_ulonglong)] * 4),
+    "pbSelfTestHoldThreshold": (_I, [C.c_float, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "pbSelfTestPairGeometry": (_I, [_U, _U, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "pbSelfTestDivision": (_I, [_U, _U, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
 }

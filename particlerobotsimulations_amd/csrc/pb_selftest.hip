@@ -30,6 +30,20 @@ __global__ __launch_bounds__(256) void k_selftest_sqrt(unsigned long long *__res
   if (seen) atomicAdd(checked, (unsigned long long)seen);
 }
 
+// the static-friction hold (pb_device.hpp PbDevParams::holdV2 / holdF2): `sqrtf(x) < c` against `x < T(c)` for EVERY
+// non-negative float bit pattern x (infinities and NaNs included), T computed on the host (pbSqrtThreshold)
+__global__ __launch_bounds__(256) void k_selftest_hold(float c, float T, unsigned long long *__restrict__ mismatches,
+                                                       unsigned long long *__restrict__ checked) {
+  const uint32_t base = (blockIdx.x * 256u + threadIdx.x) * 16u;
+  uint32_t bad = 0;
+  for (uint32_t k = 0; k < 16u; k++) {
+    const float x = __uint_as_float(base + k);
+    if ((sqrtf(x) < c) != (x < T)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+  if (threadIdx.x == 0) atomicAdd(checked, 256ull * 16ull);
+}
+
 // sampled (numerator a, numerator b, denominator d) against hipcc's a/d, b/d, inside
 // v_div_scale_f32's own "no scaling needed" region (which is pbDiv2Fast's domain)
 PB_DEV bool pbDivNoScale(uint32_t nb, uint32_t db) {
@@ -191,6 +205,20 @@ int pbSelfTest(unsigned long long div_samples, unsigned long long *sqrt_checked,
   if (sqrt_mismatches) *sqrt_mismatches = h[1];
   if (div_checked) *div_checked = h[2];
   if (div_mismatches) *div_mismatches = h[3];
+  return PB_OK;
+}
+
+int pbSelfTestHoldThreshold(float c, unsigned long long *checked, unsigned long long *mismatches) {
+  unsigned long long *d = nullptr;
+  PB_TRY(hipMalloc((void **)&d, 2 * sizeof(unsigned long long)));
+  PB_TRY(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_selftest_hold, dim3(1u << 19), dim3(256), 0, 0, c, pbSqrtThreshold(c), d + 1, d + 0);
+  PB_TRY(hipGetLastError());
+  unsigned long long h[2];
+  PB_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  PB_TRY(hipFree(d));
+  if (checked) *checked = h[0];
+  if (mismatches) *mismatches = h[1];
   return PB_OK;
 }
 

@@ -246,6 +246,18 @@ def test_fast_math_self_test(pb):
     assert r["div_mismatches"] == 0, r
 
 
+def test_static_friction_hold_thresholds_exhaustive(pb):
+    """The hold `length(v) < 0.000001f && length(F) < 2 mu g` (impl.cuh:809-811) runs as two compares of squared lengths
+    against host-computed thresholds: for the constants of the shipped configurations (and a few odd ones) the
+    device's IEEE `sqrtf(x) < c` and `x < T(c)` agree on EVERY non-negative float bit pattern, NaNs included."""
+    f = np.float32
+    consts = [1e-6, float(f(2) * f(0.4) * f(9.81 * 0.566)), float(f(2) * f(0.4) * f(9.8)),
+              float(f(2) * (f(0.4) * f(10)) * (f(9.8) * f(50))), 1.0, 3e-39, 1e30, float("inf"), 0.0, -1.0]
+    for c in consts:
+        r = pb.self_test_hold_threshold(c)
+        assert r["checked"] == 1 << 31 and r["mismatches"] == 0, (c, r)
+
+
 def test_pair_geometry_exhaustive_slices(pb):
     """pbDistUnitFast (one v_rsq_f32 for the distance, its reciprocal and the unit vector) on EVERY (d2, numerator)
     mantissa pair of two of the 64 slices of d2 in [1, 4): the first, and the last -- which holds the two d2 whose
