@@ -70,7 +70,8 @@ void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_override
  * so that a kill in mid-write loses nothing.  resume != 0: sub-batches with a complete checkpoint in the directory
  * continue from it (finished ones only hand back their rows; their members are not even placed); the others start
  * afresh.  The resumed run's rows (and final states of the sub-batches that still ran) equal the uninterrupted
- * run's bit for bit.  The directory belongs to one (nmembers, sub_batch) decomposition; Run needs `out`. */
+ * run's bit for bit.  The directory belongs to one (nmembers, sub_batch) decomposition (a resume with sub_batch -1 adopts
+ * the directory's, whatever the number of producer threads is this time); Run needs `out`. */
 void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *common_overrides,
                                            const char **member_overrides, int nmembers, int sub_batch, int host_threads,
                                            int keep_final_states, const char *checkpoint_dir, int resume);

@@ -822,6 +822,14 @@ void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *com
   // 31-member one after 1.6), at most 64 members (host memory: three sub-batches of placed members are alive)
   const int autoSub = std::min(p->threads, 64);
   p->sub = sub_batch == -1 ? std::min(autoSub, nmembers) : (sub_batch < 1 || sub_batch > nmembers) ? nmembers : sub_batch;
+  if (sub_batch == -1 && resume && checkpoint_dir && checkpoint_dir[0]) {
+    // a sweep resumed with the automatic size continues with the size it was started with, whatever the number of
+    // producer threads is this time (the directory belongs to one decomposition)
+    int m0 = 0, s0 = 0;
+    FILE *f = fopen((std::string(checkpoint_dir) + "/run.info").c_str(), "r");
+    if (f && fscanf(f, "members %d sub_batch %d", &m0, &s0) == 2 && m0 == nmembers && s0 >= 1 && s0 <= nmembers) p->sub = s0;
+    if (f) fclose(f);
+  }
   p->keepStates = keep_final_states != 0;
   p->built.assign(nmembers, nullptr);
   p->ready.assign(nmembers, 0);

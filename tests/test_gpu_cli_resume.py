@@ -136,6 +136,27 @@ def test_pipelined_ensemble_stopped_and_resumed_equals_the_uninterrupted_run(tmp
                                    resume=True)
 
 
+def test_automatic_sub_batch_resumes_with_the_size_it_started_with(tmp_path):
+    """sub_batch -1 = as many members as producer threads; a sweep started with 3 threads and resumed with 2 keeps the
+    3-member sub-batches of its checkpoint directory, and ends bit-identical to the uninterrupted run."""
+    from particlerobotsimulations_amd import ensemble
+    cfg = EX("example.cfg")
+    members = [f"seed\n{3000 + k}" for k in range(7)]
+    common = {"max_time": "18", "dump_interval": "6"}
+    a = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=-1, host_threads=3)
+    steps = a.run()
+    assert a.timings["sub_batch"] == 3 and a.timings["sub_batches"] == 3
+    b = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=-1, host_threads=3, checkpoint_dir=str(tmp_path / "b"))
+    assert b.run(700) == 700
+    b.close()
+    b2 = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=-1, host_threads=2, checkpoint_dir=str(tmp_path / "b"),
+                                    resume=True)
+    assert b2.run() == steps and b2.timings["sub_batch"] == 3
+    assert np.array_equal(b2.rows.view(np.uint32), a.rows.view(np.uint32))
+    b2.close()
+    a.close()
+
+
 def test_cxx_ensemble_runner_killed_and_resumed(tmp_path):
     """bin/particlebot_ensemble --checkpoint DIR, SIGKILLed in mid-sweep, then --resume DIR: the gathered rows equal
     the uninterrupted sweep's bit for bit (world of one rank through the real RCCL calls)."""
