@@ -308,6 +308,16 @@ class DevicePrewarm:
                              "steps, to bring the device out of its idle power state; not part of warmup/steps"}
         return self.info
 
+    def keep_busy(self, ms):
+        """Enqueue ~ms of scratch steps WITHOUT waiting for them (the device stays loaded while the host is elsewhere)."""
+        if self.scratch is not None and self.info["steps"] > 0:
+            per_step = self.info["ms"] / self.info["steps"]
+            self.scratch.step(max(1, min(int(ms / max(per_step, 1e-3)), 2000)))
+
+    def synchronize(self):
+        if self.scratch is not None:
+            self.scratch.synchronize()
+
     def done(self):
         if self.scratch is not None:
             self.scratch.close()
@@ -740,16 +750,31 @@ def host_info():
     return {"glibc": L.pbHostLibcVersion().decode(), "cpus": cpus}
 
 
+_JSON_FD = None   # with a process group: the original stdout (fd 1 itself is pointed at stderr, see divert_stdout)
+
+
+def divert_stdout():
+    """RCCL prints a five-line version banner to stdout when its communicator is created (this build does so with
+    NCCL_DEBUG unset; NCCL_DEBUG_FILE does not move it).  stdout carries ONE line, the JSON: everything else written to
+    file descriptor 1 from here on -- by C libraries or by Python -- goes to stderr."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(out):
-    # the ONE JSON line goes last: push out whatever C libraries (RCCL's version banner) still hold
-    # in stdio buffers first
     sys.stdout.flush()
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    print(json.dumps(out), flush=True)
+    if _JSON_FD is not None:
+        os.write(_JSON_FD, (json.dumps(out) + "\n").encode())
+    else:
+        print(json.dumps(out), flush=True)
 
 
 def spawn_ranks(args):
@@ -825,6 +850,7 @@ def main():
         # torch first: its bundled HIP runtime must be the one instance in the process
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        divert_stdout()
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch
@@ -864,12 +890,27 @@ def main():
 
     prewarm = warm.run()
     sim.step(args.warmup)
-    barrier()
+    # The timed region: exactly K steps with a barrier + device synchronisation on both sides, MAX over ranks.
+    # With a process group the OPENING barrier is entered while the device still works -- the W warm-up steps and a
+    # few ms more of the scratch arena, all asynchronous -- and the synchronisation comes after it: an RCCL barrier
+    # leaves the device idle for some hundred microseconds otherwise, and the first timed steps then run at idle
+    # clocks (measured with --force-dist, --steps 20: 1.80 ms of device time for the 20 steps instead of 1.58).  The
+    # clock is read when this rank's K steps have completed, BEFORE the closing barrier (MAX over ranks is the time
+    # at which the last rank finished; the barrier's own latency, ~0.2 ms, is not part of any rank's K steps).
+    if dist is not None:
+        warm.keep_busy(3.0)
+        dist.barrier()
+        warm.synchronize()
+        sim.synchronize()
+        torch.cuda.synchronize()
+    else:
+        barrier()
     s0 = sim.stats()
     t0 = time.perf_counter()
     done, dev_ms = sim.step_timed(args.steps)
-    barrier()
+    sim.synchronize()
     wall = time.perf_counter() - t0
+    barrier()
     s1 = sim.stats()
     assert done == args.steps, (done, args.steps)
     # a timed region under 50 ms of device time (the driver's --steps 20 is ~2 ms) is followed at once by one of

@@ -117,8 +117,14 @@ def test_arena_line_through_rccl_with_one_rank_and_gpus_flag_is_checked():
     """The N > 1 code path of the default workload on one GPU: --force-dist initialises RCCL (world 1),
     runs the barrier / max-over-ranks all_reduce / all_gather of the arena summaries.  And `--gpus 2`
     without a launcher on a one-GPU box refuses loudly instead of silently running one arena."""
-    d = _bench("--bots", "150000", "--steps", "40", "--warmup", "10", "--force-dist", "--no-cpu-baseline",
-               "--no-survey-literal", "--no-streamlined", "--no-large-arena", "--no-blob", "--e2e-steps", "300")
+    raw = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bots", "150000", "--steps", "40", "--warmup",
+                          "10", "--force-dist", "--no-cpu-baseline", "--no-survey-literal", "--no-streamlined",
+                          "--no-large-arena", "--no-blob", "--e2e-steps", "300"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert raw.returncode == 0, raw.stderr[-2000:]
+    lines = [l for l in raw.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:3]      # ONE line on stdout: RCCL's version banner goes to stderr
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and len(d["summaries_time_comx_comy"]) == 1 and d["value"] > 0
     assert "RCCL world size 1" in d["ensemble_leg"]["config"]["parallelism"]   # the leg's gather went over RCCL
     import torch
