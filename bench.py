@@ -747,7 +747,8 @@ def host_info():
         cpus = len(os.sched_getaffinity(0))
     except Exception:
         cpus = os.cpu_count()
-    return {"glibc": L.pbHostLibcVersion().decode(), "cpus": cpus}
+    return {"glibc": L.pbHostLibcVersion().decode(), "cpus": cpus,
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
 
 
 _JSON_FD = None   # with a process group: the original stdout (fd 1 itself is pointed at stderr, see divert_stdout)
@@ -831,6 +832,12 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path")
     args = ap.parse_args()
+    # HIP gives a new stream the least-used of GPU_MAX_HW_QUEUES (default 4) hardware queues.  Next to the streams of
+    # PyTorch and RCCL (any run with a process group) the two batches of the configs[3] leg -- one stream each, meant
+    # to overlap -- landed on ONE queue and serialised: 1.68 s end to end instead of 0.95 (round 3, --force-dist).
+    # With 6 or more queues they do not; nothing else in this file changes with it (measured).  Must be in the
+    # environment before the HIP runtime initialises; the ranks torchrun starts inherit it.  Disclosed in `host`.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.sub_batch is not None and args.workload in FULL_RUN:
         FULL_RUN[args.workload]["sub_batch"] = args.sub_batch
     if args.members_per_gpu is None:
