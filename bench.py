@@ -614,8 +614,10 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
         barrier()
         t0 = time.perf_counter()
         done = drive(nsteps)
+        for e in ens:
+            e.synchronize()
+        wall = time.perf_counter() - t0   # this rank's steps are complete; MAX over ranks below; the barrier after it
         barrier()
-        wall = time.perf_counter() - t0
         assert all(d == nsteps for d in done), (done, nsteps)
         if dist is not None:
             t = torch.tensor([wall], dtype=torch.float64, device="cuda")
