@@ -867,6 +867,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == world
+        dist.barrier()   # (the communicator and RCCL's kernels are set up here, not inside a measurement's first barrier)
 
     import particlerobotsimulations_amd as pb
 
