@@ -284,6 +284,12 @@ int main(int argc, char **argv) {
       return 1;
     }
   }
+  // RCCL prints a version banner to stdout when the communicator is created; stdout carries ONE line, rank 0's JSON:
+  // file descriptor 1 points at stderr from here on, the JSON goes to the saved descriptor
+  fflush(stdout);
+  const int jsonFd = dup(1);
+  if (jsonFd >= 0) (void)dup2(2, 1);
+  FILE *const jsonOut = jsonFd >= 0 ? fdopen(jsonFd, "w") : stdout;
   ncclComm_t comm;
   CHECK_NCCL(ncclCommInitRank(&comm, world, id, rank));
   hipStream_t stream;
@@ -377,7 +383,7 @@ int main(int argc, char **argv) {
       sum2 += d * d;
     }
     const double mean = sum / members, var = sum2 / members - mean * mean;
-    printf("{\"cfg\": \"%s\", \"members\": %d, \"n_gpus\": %d, \"bots_per_member\": %d, \"steps_per_member\": %ld, "
+    fprintf(jsonOut, "{\"cfg\": \"%s\", \"members\": %d, \"n_gpus\": %d, \"bots_per_member\": %d, \"steps_per_member\": %ld, "
            "\"rows_per_member\": %d, \"wall_s\": %.6f, \"sims_per_s\": %.6g, \"particle_steps_per_s\": %.6g, "
            "\"progress_toward_light_mean\": %.9g, \"progress_toward_light_std\": %.9g, "
            "\"pipeline_rank0\": {\"sub_batch\": %d, \"sub_batches\": %d, \"host_threads\": %d, \"placement_cpu_s\": %.4f, "
@@ -387,6 +393,7 @@ int main(int argc, char **argv) {
            (double)members * hs[2] * hs[3] / wall, mean, sqrt(var > 0 ? var : 0), tm.sub_batch, tm.sub_batches,
            tm.host_threads, tm.placement_cpu_s, tm.placement_wait_s, tm.upload_s, tm.device_s, resume ? "true" : "false",
            block);
+    fflush(jsonOut);
     if (!outPath.empty()) {
       FILE *f = fopen(outPath.c_str(), "wb");
       if (!f || fwrite(all.data(), sizeof(float), (size_t)members * allRows * 4, f) != (size_t)members * allRows * 4) {

@@ -323,7 +323,9 @@ def test_cxx_rccl_ensemble_runner_equals_python_layer(tmp_path):
                         "dump_interval", "0.5", "--sweep", "nDead", "0", "10", "20", "--out", str(out)],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    info = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:3]      # ONE line on stdout (RCCL's version banner goes to stderr)
+    info = json.loads(lines[0])
     assert info["members"] == 6 and info["n_gpus"] == 1 and info["bots_per_member"] == 100
     got = np.fromfile(out, np.float32).reshape(6, info["rows_per_member"], 4)
     over = [ensemble.member_overrides(k, 500, ("nDead", ["0", "10", "20"])) for k in range(6)]
