@@ -118,6 +118,37 @@ for w in waves:
     tot["flat_contact"] += int(Mf.any(axis=0).sum())
     tot["flat_switch_trips"] += int(Sw.any(axis=0).sum())
     tot["lanes"] += 64
+# PFS: the flattened walk with the 256 bots of a workgroup's tile dealt to its four waves by list length (longest
+# first), so that a wave's lanes finish together
+pfs = dict(trips=0, contact=0, switch=0, pairs=0)
+tiles = rng.choice(n // 256, size=min(100, n // 256), replace=False)
+for tI in tiles:
+    sl = np.arange(tI * 256, tI * 256 + 256)
+    lists, ends_all = [], []
+    for s in sl:
+        parts = []
+        for r in range(-2, 3):
+            row = ((gy[s] + r) & (G - 1)) * G
+            lo, hi = cellS[row + ((gx[s] - 2) & (G - 1))], cellS[row + ((gx[s] + 2) & (G - 1)) + 1]
+            j = np.arange(lo, hi)
+            d = np.hypot(spos[j, 0] - spos[s, 0], spos[j, 1] - spos[s, 1])
+            parts.append((d < srad[j] + srad[s]) & (j != s))
+        lists.append(np.concatenate(parts))
+        ends_all.append(np.cumsum([len(x) for x in parts])[:-1])
+    order2 = np.argsort([-len(c) for c in lists], kind="stable")
+    for w4 in range(4):
+        idx = order2[w4 * 64:(w4 + 1) * 64]
+        Lf = max(len(lists[i]) for i in idx)
+        Mf = np.zeros((64, Lf), bool)
+        Sw = np.zeros((64, Lf), bool)
+        for a, i in enumerate(idx):
+            Mf[a, :len(lists[i])] = lists[i]
+            e = ends_all[i]
+            Sw[a, e[e < Lf]] = True
+            pfs["pairs"] += len(lists[i])
+        pfs["trips"] += Lf
+        pfs["contact"] += int(Mf.any(axis=0).sum())
+        pfs["switch"] += int(Sw.any(axis=0).sum())
 W = len(waves)
 pairs_per_bot = tot["pairs"] / tot["lanes"]
 print(f"{n} bots after {steps} steps; {W} waves sampled; candidate pairs per bot {pairs_per_bot:.1f}, "
@@ -134,5 +165,11 @@ print(f"PF (per-lane flattened walk): trips per wave {tot['flat_trips'] / W:.1f}
       f"{tot['pairs'] / 64 / tot['flat_trips']:.3f} against {tot['pairs'] / 64 / tot['p0_trips']:.3f}), with the contact "
       f"block {tot['flat_contact'] / tot['flat_trips']:.2f}, with a range switch {tot['flat_switch_trips'] / tot['flat_trips']:.2f}; "
       f"modelled VALU per wave {pf / W:.0f}  ({pf / p0:.3f} of P0)")
+WS = 4 * len(tiles)
+pfs_cost = pfs["trips"] * (A + FAR + OVH + 1) + pfs["contact"] * CON + pfs["switch"] * SWITCH
+print(f"PFS (flattened walk, lanes dealt to the tile's four waves by list length): trips per wave {pfs['trips'] / WS:.1f} "
+      f"(lane utilisation {pfs['pairs'] / 64 / pfs['trips']:.3f}), with the contact block {pfs['contact'] / pfs['trips']:.2f}, "
+      f"with a range switch {pfs['switch'] / pfs['trips']:.2f}; modelled VALU per wave {pfs_cost / WS:.0f}  "
+      f"({(pfs_cost / WS) / (p0 / W):.3f} of P0)")
 ideal = tot["pairs"] / 64 * (A + OVH) + (tot["pairs"] - tot["contacts"]) / 64 * FAR + tot["contacts"] / 64 * CON
 print(f"divergence-free bound: {ideal / W:.0f} ({ideal / p0:.3f} of P0)")
