@@ -762,9 +762,13 @@ def divert_stdout():
     file descriptor 1 from here on -- by C libraries or by Python -- goes to stderr."""
     global _JSON_FD
     if _JSON_FD is None:
-        sys.stdout.flush()
-        _JSON_FD = os.dup(1)
-        os.dup2(2, 1)
+        try:
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            _JSON_FD = saved
+        except OSError:
+            _JSON_FD = None   # (no usable stderr: keep stdout as it is; the JSON line is still the last one)
 
 
 def emit(out):
