@@ -91,6 +91,7 @@ def usable_cpus():
 
 
 _lib = None
+_variants = {}
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
@@ -103,7 +104,38 @@ def lib():
     if _lib is not None:
         return _lib
     build()
-    L = C.CDLL(_SO)
+    _lib = _bind(_SO)
+    return _lib
+
+
+BRACKET_VARIANTS = ("fma", "fma_powf")
+
+
+def variant_lib(name):
+    """A BRACKET build of the same source (oracle/Makefile): "fma" = kernel functions contracted
+    into FMAs as nvcc's default -fmad=true does, "fma_powf" = that plus exp2f(2*log2f(x)) at the two
+    __powf sites.  These are not the oracle: they measure how far a legitimately different build
+    of the reference's arithmetic drifts from it (tests/test_fma_bracket.py)."""
+    if name in (None, "exact"):
+        return lib()
+    if name not in BRACKET_VARIANTS:
+        raise ValueError(name)
+    if name not in _variants:
+        so = os.path.join(_HERE, f"libpb_oracle_{name}.so")
+        src = os.path.join(_HERE, "pb_oracle.c")
+        if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < os.path.getmtime(src)):
+            subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)], stdout=subprocess.DEVNULL)
+        L = _bind(so)
+        want = {"fma": b"fma", "fma_powf": b"fma+powf"}[name]
+        if L.orc_build_variant() != want:
+            raise RuntimeError(f"{so} reports build variant {L.orc_build_variant()!r}, expected {want!r}")
+        _variants[name] = L
+    return _variants[name]
+
+
+def _bind(so):
+    L = C.CDLL(so)
+    L.orc_build_variant.restype = C.c_char_p
     L.orc_params_defaults.argtypes = [_PP]
     L.orc_set_param.argtypes = [_PP, C.c_char_p, C.c_char_p]
     L.orc_load_cfg.argtypes = [_PP, C.c_char_p]
@@ -150,7 +182,6 @@ def lib():
     L.orc_sim_load_from_file.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_sim_load_from_file.restype = C.c_int
     L.orc_set_num_threads(usable_cpus())
-    _lib = L
     return L
 
 
@@ -197,16 +228,17 @@ class Sim:
             "absForce_r": (5, np.float32, 1), "dead": (6, np.int32, 1),
             "hash": (7, np.uint32, 1), "index": (8, np.uint32, 1)}
 
-    def __init__(self, P, reset=True, hex=False):
+    def __init__(self, P, reset=True, hex=False, variant=None):
         self.P = P
         self.n = int(P.nCells)
-        self._h = lib().orc_sim_create(C.byref(P))
+        self._L = variant_lib(variant)  # None: the oracle; "fma"/"fma_powf": a bracket build
+        self._h = self._L.orc_sim_create(C.byref(P))
         if reset:
-            lib().orc_sim_reset(self._h, 1 if hex else 0)
+            self._L.orc_sim_reset(self._h, 1 if hex else 0)
 
     def close(self):
         if self._h:
-            lib().orc_sim_destroy(self._h)
+            self._L.orc_sim_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -218,7 +250,7 @@ class Sim:
     def view(self, name):
         """numpy VIEW (no copy) of an internal array, original index order."""
         which, dt, w = self._ARR[name]
-        ptr = lib().orc_sim_array(self._h, which)
+        ptr = self._L.orc_sim_array(self._h, which)
         buf = (C.c_byte * (self.n * w * 4)).from_address(ptr)
         a = np.frombuffer(buf, dtype=dt)
         return a.reshape(self.n, w) if w > 1 else a
@@ -231,19 +263,19 @@ class Sim:
 
     @property
     def time(self):
-        return lib().orc_sim_time(self._h)
+        return self._L.orc_sim_time(self._h)
 
     @time.setter
     def time(self, t):
-        lib().orc_sim_set_time(self._h, float(t))
+        self._L.orc_sim_set_time(self._h, float(t))
 
     def force_sort_once(self):
-        lib().orc_sim_force_sort_once(self._h)
+        self._L.orc_sim_force_sort_once(self._h)
 
     def update(self, dt=None, sort_interval=None):
         dt = self.P.timestep if dt is None else dt
         si = self.P.sort_interval if sort_interval is None else sort_interval
-        return lib().orc_sim_update(self._h, dt, si)
+        return self._L.orc_sim_update(self._h, dt, si)
 
     def run(self, steps, dt=None, sort_interval=None):
         for _ in range(steps):
@@ -258,7 +290,7 @@ class Sim:
         if path_or_none is not None:
             fp = _libc.fopen(os.fsencode(path_or_none), mode.encode())
         try:
-            return lib().orc_sim_dump(self._h, fp, di, tt, 0)
+            return self._L.orc_sim_dump(self._h, fp, di, tt, 0)
         finally:
             if fp:
                 _libc.fclose(fp)
@@ -268,6 +300,6 @@ class Sim:
         if not fp:
             raise FileNotFoundError(path)
         try:
-            return lib().orc_sim_load_from_file(self._h, fp)
+            return self._L.orc_sim_load_from_file(self._h, fp)
         finally:
             _libc.fclose(fp)

@@ -17,6 +17,40 @@
 #include <omp.h>
 #endif
 
+/*
+ * BRACKET BUILDS (oracle/Makefile: libpb_oracle_fma.so, libpb_oracle_fma_powf.so).  The reference is
+ * compiled by nvcc -O3 with its default -fmad=true (/root/reference/Makefile:79-89 sets no
+ * -fmad=false) and calls the fast intrinsic __powf at particlebot_kernel_impl.cuh:586,589.  Neither
+ * nvcc's contraction choices nor __powf's bits can be pinned in this image, so two more builds of
+ * THIS file bracket them:
+ *   -DORC_BRACKET_FMA   the kernel functions (everything between the two "device code" markers
+ *                       below) are compiled with fp-contract=fast + FMA instructions; config,
+ *                       placement, the host loop and the dump stay contract-off like the exact build
+ *                       (nvcc hands host code to g++ unchanged)
+ *   -DORC_BRACKET_POWF  additionally x*x -> exp2f(2*log2f(x)) at the two __powf sites (the published
+ *                       definition of __powf(x,y) = exp2f(y * __log2f(x)); glibc's exp2f/log2f stand
+ *                       in for the hardware approximations, so this is a LOWER bound on its error)
+ * The exact build (neither macro) is the oracle; the bracket builds only measure how far a
+ * legitimately different build of the same source drifts from it (tests/test_fma_bracket.py).
+ */
+#if defined(ORC_BRACKET_POWF)
+#define ORC_POW2(x) exp2f(2.0f * log2f(x))
+#else
+#define ORC_POW2(x) ((x) * (x))
+#endif
+
+const char *orc_build_variant(void) {
+#if defined(ORC_BRACKET_FMA) && defined(ORC_BRACKET_POWF)
+  return "fma+powf";
+#elif defined(ORC_BRACKET_FMA)
+  return "fma";
+#elif defined(ORC_BRACKET_POWF)
+  return "powf";
+#else
+  return "exact";
+#endif
+}
+
 /* below this many bots every loop runs on the calling thread (fork/join costs more than the work) */
 #define ORC_OMP_MIN_N 20000u
 
@@ -26,9 +60,6 @@
 /* float2 helpers with the exact operation order of include/helper_math.h                       */
 /* ------------------------------------------------------------------------------------------ */
 
-/* helper_math.h:1244 dot = a.x*b.x + a.y*b.y ; :1287 length = sqrtf(dot(v,v)) */
-static inline float dot2(float ax, float ay, float bx, float by) { return ax * bx + ay * by; }
-static inline float len2(float x, float y) { return sqrtf(dot2(x, y, x, y)); }
 
 /* particlebot.cpp:32-34 host-side length(): glibc powf on purpose */
 static inline float host_length(float x, float y) { return powf(powf(x, 2.0f) + powf(y, 2.0f), 0.5f); }
@@ -242,6 +273,18 @@ void orc_params_derive(OrcParams *p, uint32_t grid_override, float arena_half) {
 /* ------------------------------------------------------------------------------------------ */
 /* kernels                                                                                      */
 /* ------------------------------------------------------------------------------------------ */
+
+/* >>> device code: what nvcc compiles for the GPU (contracted in the ORC_BRACKET_FMA build) >>> */
+#if defined(ORC_BRACKET_FMA)
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=fast")
+#pragma GCC target("fma")
+#endif
+
+/* helper_math.h:1244 dot = a.x*b.x + a.y*b.y ; :1287 length = sqrtf(dot(v,v)) -- device-side
+ * helpers (the placement uses host_length above) */
+static inline float dot2(float ax, float ay, float bx, float by) { return ax * bx + ay * by; }
+static inline float len2(float x, float y) { return sqrtf(dot2(x, y, x, y)); }
 
 /* particlebot_kernel_impl.cuh:53-103 integrate_functor, launched by particlebot_cuda.cu:145-160 */
 void orc_integrateSystem(const OrcParams *P, float *pos, float *vel, const float *rad, float dt,
@@ -478,6 +521,9 @@ void orc_updatePhase(const OrcParams *P, const float *pos, float *phase, float s
   }
 }
 
+#if defined(ORC_BRACKET_FMA)
+#pragma GCC pop_options /* host code */
+#endif
 /* particlebot.cpp:215-228 host loop */
 void orc_minmax_light_distance(const OrcParams *P, const float *pos, uint32_t n, float *min_d,
                                float *max_d) {
@@ -495,6 +541,11 @@ void orc_minmax_light_distance(const OrcParams *P, const float *pos, uint32_t n,
   *min_d = mn;
   *max_d = mx;
 }
+#if defined(ORC_BRACKET_FMA)
+#pragma GCC push_options /* device code again */
+#pragma GCC optimize("fp-contract=fast")
+#pragma GCC target("fma")
+#endif
 
 /* impl.cuh:541-594 collideSpheres */
 static inline void pair_force(const OrcParams *P, float ax, float ay, float bx, float by, float avx,
@@ -528,11 +579,11 @@ static inline void pair_force(const OrcParams *P, float ax, float ay, float bx, 
       tx += min_attr * (rx / dist);
       ty += min_attr * (ry / dist);
     } else if (gap < int2) {
-      const float c = min_attr + (attraction / (int2 * int2) - min_attr) / (int2 - int1) * (gap - int1);
+      const float c = min_attr + (attraction / ORC_POW2(int2) - min_attr) / (int2 - int1) * (gap - int1); /* :586 __powf */
       tx += c * (rx / dist);
       ty += c * (ry / dist);
     } else {
-      const float g2 = gap * gap;
+      const float g2 = ORC_POW2(gap); /* :589 __powf(dist - collideDist, 2.0f) */
       tx += attraction * (rx / dist) / g2;
       ty += attraction * (ry / dist) / g2;
     }
@@ -712,6 +763,12 @@ void orc_collide(const OrcParams *P, float *newVel, float *absForce_a, float *ab
     absForce_r[orig] = fr;
   }
 }
+
+#if defined(ORC_BRACKET_FMA)
+#pragma GCC pop_options
+#endif
+/* <<< end of device code <<< (the phase-noise generators below are this repository's own or a
+ * restatement of cuRAND's: not part of what the bracket measures; bracket runs use phase_std 0) */
 
 /* ------------------------------------------------------------------------------------------ */
 /* phase noise: PB-RNG v1 (own counter RNG + polynomial Box-Muller; deterministic in fp32)      */

@@ -148,6 +148,8 @@ void *orc_sim_array(OrcSim *s, int which);
 /* number of worker threads used by the OpenMP loops (1 when built without OpenMP) */
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
+/* "exact" for the oracle; "fma" / "fma+powf" for the bracket builds (pb_oracle.c header, oracle/Makefile) */
+const char *orc_build_variant(void);
 
 /* XORWOW test hooks (the generator-2 section of pb_oracle.c): raw outputs of
  * curand_init(seed, subsequence, 0); normals of bots 0..nbots-1 over `draws` phase updates
