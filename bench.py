@@ -42,6 +42,94 @@ LATTICE_PITCH = 0.155
 HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+# ---- --dry-run-device (test-only) --------------------------------------------------------------------------------
+# The multi-rank choreography of this file -- spawn_ranks, the rendezvous, barriers, the MAX all-reduce, the gather of
+# summary rows, ONE JSON line from rank 0 -- must be exercised before the driver's SCALE run does it, and this
+# container has no GPU.  With --dry-run-device the process group is gloo on CPU tensors and the device is replaced by
+# the stand-ins below: the arena by a counter (_DrySim), an ensemble's stepping by the pipeline's dry-run consumer
+# (pbEnsemblePipelineDryRun: members are PLACED for real, by the producer pool, and their rows are made from the
+# checksum of the placed state).  Every number in a dry-run line is meaningless and the line says `dry_run: true`;
+# tests/test_bench_multirank.py reads its structure.
+DRY = False
+
+
+def dev_sync(torch):
+    if not DRY:
+        torch.cuda.synchronize()
+
+
+def dist_device():
+    return "cpu" if DRY else "cuda"
+
+
+class _DrySim:
+    def __init__(self, params, wall_half=0.0, keepalive=None):
+        self.n, self.time, self._steps, self._variant = int(params.nCells), 0.0, 0, 2
+
+    def set_force_variant(self, v):
+        self._variant = v
+
+    def set_lanes_per_bot(self, lanes):
+        pass
+
+    set_resident = set_force_sums = set_lanes_per_bot
+
+    def set_state(self, **kw):
+        pass
+
+    def step(self, k, *a):
+        self._steps += k
+        self.time += 0.01 * k
+        return k
+
+    def step_timed(self, k, *a):
+        return self.step(k), 0.08 * k
+
+    def synchronize(self):
+        pass
+
+    close = synchronize
+
+    def centroid(self):
+        return 0.0, 0.0
+
+    def stats(self):
+        return {"steps": self._steps, "fused_launches": self._steps, "plain_launches": 0, "state_launches": 0, "resorts": 0,
+                "phase_updates": 0, "resident_launches": 0}
+
+    def config(self):
+        return {"force_variant": self._variant, "force_kind": 0, "lanes_per_bot": 1, "resident": 0, "attraction_sums": 0,
+                "dead_sum_form": 1}
+
+
+class _DryPb:
+    Sim = _DrySim
+
+
+class _DryLocalEnsemble:
+    """ensemble.LocalEnsemble without a device: members placed by the pipeline, rows from their checksums"""
+
+    def __init__(self, cfg, over, common):
+        from particlerobotsimulations_amd import ensemble
+        self._p = ensemble.PipelinedEnsemble(cfg, over, common)
+        self.m = len(over)
+        self._p.run_dry(0)
+        self.n = getattr(self._p, "n", 0)
+
+    def run_steps(self, k):
+        return k
+
+    def synchronize(self):
+        pass
+
+    @property
+    def rows(self):
+        return self._p.rows
+
+    def close(self):
+        self._p.close()
+
+
 def square_lattice(n, pitch):
     """side x side bots (row-major, bot i at column i % side, row i // side), centred on the origin."""
     import numpy as np
@@ -507,8 +595,24 @@ def ensemble_batches(workload, rank, world, members_per_gpu, members_total=None,
     return [(ex("example_dead_cells.cfg"), common, over, ids)]
 
 
+def pipeline_bound(tm, members):
+    """host-bound or device-bound?  What the host needs for this rank's members with the producer threads it has
+    (placement CPU-seconds / threads) against what the device needs (upload + stepping + read-backs)."""
+    host_s = tm["placement_cpu_s"] / max(tm["host_threads"], 1)
+    dev_s = tm["device_s"] + tm["upload_s"]
+    return {"bound": "host" if host_s > dev_s else "device", "host_s": host_s, "device_s": dev_s,
+            "placement_cpu_s_per_member": tm["placement_cpu_s"] / max(members, 1), "members": members,
+            "producer_threads": tm["host_threads"], "device_waited_for_host_s": tm["placement_wait_s"],
+            "producers_pinned_to_gpu_numa_node": bool(tm.get("pinned")), "numa_node": tm.get("numa_node", -1),
+            "oversubscription": (tm["placement_thread_wall_s"] / tm["placement_cpu_s"]
+                                 if tm.get("placement_cpu_s", 0) > 0 else None),
+            "note": "host_s = placement CPU-seconds of this rank's members / its producer threads; bound = host when "
+                    "that exceeds the device's time for them (the wall time is then placement, not stepping); "
+                    "oversubscription = producers' wall time / CPU time (1 = every producer had a core)"}
+
+
 def ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu=None, members_total=None, max_steps=None,
-                        host_threads=0):
+                        host_threads=0, extra_common=None):
     """One ensemble run END TO END, as a user of bin/particlebot_ensemble experiences it: from the moment the
     members exist only as override strings to the moment rank 0 holds every member's summary rows -- host placement
     (overlapped with device stepping by the sub-batch pipeline, pbEnsemblePipeline*), state upload, every timestep
@@ -525,29 +629,44 @@ def ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu=None
 
     def barrier():
         if dist is not None:
-            torch.cuda.synchronize()
+            dev_sync(torch)
             dist.barrier()
     barrier()
     t0 = time.perf_counter()
-    pipes = [ensemble.PipelinedEnsemble(cfg, over, common, sub_batch=full["sub_batch"], host_threads=host_threads)
+    res = ensemble.host_resources()
+    if host_threads <= 0 and len(batches) > 1:
+        # this rank's pipelines place at the same time: they share the rank's producer threads (one core stays
+        # with the threads that drive the device) instead of each taking all of them
+        host_threads = max(1, (res["host_threads"] - 1) // len(batches))
+    common_extra = dict(extra_common or {})
+    pipes = [ensemble.PipelinedEnsemble(cfg, over, dict(common, **common_extra), sub_batch=full["sub_batch"],
+                                        host_threads=host_threads)
              for cfg, common, over, _ in batches]   # placement starts here, on the producer threads
     done = [0] * len(pipes)
+    errors = [None] * len(pipes)
 
     def one(i):
-        done[i] = pipes[i].run(steps_cap)
+        try:
+            done[i] = pipes[i].run_dry(steps_cap) if DRY else pipes[i].run(steps_cap)
+        except BaseException as e:   # re-raised on the main thread below: a leg with a failed pipeline has no value
+            errors[i] = e
     th = [threading.Thread(target=one, args=(i,)) for i in range(1, len(pipes))]
     for t in th:
         t.start()
     one(0)
     for t in th:
         t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    assert all(d == done[0] and d > 0 for d in done), done
     total_members = members_total if members_total is not None else members_per_gpu * world
     gathered = [ensemble.gather_summaries(p.rows, total_members, rank, world, dist,
-                                          "cuda" if dist is not None else "cpu") for p in pipes]
+                                          dist_device() if dist is not None else "cpu") for p in pipes]
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device=dist_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     timings = [p.timings for p in pipes]
@@ -566,6 +685,8 @@ def ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu=None
             "rows_gathered": [list(g.shape) for g in gathered],
             "last_rows_time_comx_comy_dist": [[[float(x) for x in r] for r in g[:4, -1]] for g in gathered],
             "pipeline_rank0": timings,
+            "bound_rank0": [pipeline_bound(tm, p.m) for tm, p in zip(timings, pipes)] if not DRY else None,
+            "placement": (extra_common or {}).get("pb_placement", "reference rule (CONFIG_RANDOM, particlebot.cpp:612-748)"),
             "host_share_rank0": [tm["placement_wait_s"] / max(tm["wall_s"], 1e-9) for tm in timings],
             "note": "placement_wait_s is the time the device-driving thread waited for the host (the unhidden part of "
                     "placement); placement_cpu_s is what the host spent in all; FULL configuration length unless "
@@ -573,7 +694,7 @@ def ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu=None
 
 
 def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, rank, world, dist, torch,
-                     members_total=None, end_to_end=True, e2e_steps=None, strong_total=None):
+                     members_total=None, end_to_end=True, e2e_steps=None, strong_total=None, host_threads=0):
     """K timesteps of an ensemble workload on every rank (member k on rank k mod N), then the path's one
     exchange (the summary rows, over RCCL when there is a process group); then (end_to_end) the same ensemble run
     end to end at full length through the placement/stepping pipeline.  Collective: every rank calls
@@ -585,7 +706,7 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
     warm = DevicePrewarm(pb, 250_000, LATTICE_PITCH, prewarm_ms)
     batches = ensemble_batches(workload, rank, world, members_per_gpu, members_total)
     t_place = time.perf_counter()
-    ens = [ensemble.LocalEnsemble(cfg, over, common) for cfg, common, over, _ in batches]
+    ens = [(_DryLocalEnsemble if DRY else ensemble.LocalEnsemble)(cfg, over, common) for cfg, common, over, _ in batches]
     t_place = time.perf_counter() - t_place
 
     def drive(nsteps):
@@ -607,7 +728,7 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
         for e in ens:
             e.synchronize()
         if dist is not None:
-            torch.cuda.synchronize()
+            dev_sync(torch)
             dist.barrier()
 
     def timed(nsteps):
@@ -620,7 +741,7 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
         barrier()
         assert all(d == nsteps for d in done), (done, nsteps)
         if dist is not None:
-            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall], dtype=torch.float64, device=dist_device())
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         return wall
@@ -638,16 +759,32 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
     # the path's only exchange: every member's summary rows, gathered once over RCCL
     total_members = members_total if members_total is not None else members_per_gpu * world
     gathered = [ensemble.gather_summaries(e.rows, total_members, rank, world, dist,
-                                          "cuda" if dist is not None else "cpu") for e in ens]
+                                          dist_device() if dist is not None else "cpu") for e in ens]
     bots = [e.n for e in ens]
     mine = [e.m for e in ens]
     for e in ens:
         e.close()
     e2e = strong = None
     if end_to_end:
-        e2e = ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu, members_total, e2e_steps)
+        e2e = ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu, members_total, e2e_steps,
+                                  host_threads=host_threads)
         if strong_total is not None and members_total is None:
-            strong = ensemble_end_to_end(workload, rank, world, dist, torch, None, strong_total, e2e_steps)
+            strong = ensemble_end_to_end(workload, rank, world, dist, torch, None, strong_total, e2e_steps,
+                                         host_threads=host_threads)
+        # When the host is the limit (few cores per rank: the reference's placement rule costs 0.85-1.6 CPU-seconds per
+        # 10^5-bot member) the same run is repeated with the O(N) generator (pb_placement fastblob), so
+        # that the line shows both what the reference's rule costs here and what the device can do.  Every rank takes
+        # the same decision: rank 0's verdict is broadcast.
+        fast = None
+        if workload == "ensemble5" and not DRY:
+            host_bound = bool(e2e and any(b["bound"] == "host" for b in e2e["bound_rank0"]))
+            if dist is not None:
+                flag = torch.tensor([1 if host_bound else 0], dtype=torch.int32, device=dist_device())
+                dist.broadcast(flag, src=0)
+                host_bound = bool(flag.item())
+            if host_bound:
+                fast = ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu, members_total, e2e_steps,
+                                           host_threads=host_threads, extra_common={"pb_placement": "fastblob"})
     if rank != 0:
         return None, batches
     all_bots = sum(b * total_members for b in bots)      # bots stepped per timestep over all ranks
@@ -684,14 +821,21 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
         out["sims_per_s_end_to_end"] = e2e["sims_per_s_end_to_end"]
     if strong is not None:
         out["strong_end_to_end"] = strong
+    if end_to_end and workload == "ensemble5" and e2e is not None and not DRY:
+        out["end_to_end_bound"] = "host" if any(b["bound"] == "host" for b in e2e["bound_rank0"]) else "device"
+        if fast is not None:
+            out["end_to_end_fastblob"] = fast
     return out, batches
 
 
 def run_ensemble_workload(args, rank, world, dist, torch):
     import particlerobotsimulations_amd as pb
+    if DRY:
+        pb = _DryPb
     res, batches = measure_ensemble(pb, args.workload, args.members_per_gpu, args.steps, args.warmup, args.prewarm_ms,
                                     rank, world, dist, torch, members_total=args.members_total,
-                                    end_to_end=not args.no_end_to_end, e2e_steps=args.e2e_steps)
+                                    end_to_end=not args.no_end_to_end, e2e_steps=args.e2e_steps,
+                                    host_threads=args.host_threads)
     if rank == 0:
         out = {"metric": "particle-steps/sec at 10^6 bots; achieved HBM GB/s vs peak; 1/2/4/8-GPU ensemble",
                "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -749,7 +893,13 @@ def host_info():
         cpus = len(os.sched_getaffinity(0))
     except Exception:
         cpus = os.cpu_count()
+    from particlerobotsimulations_amd import ensemble
+    res = ensemble.host_resources()
     return {"glibc": L.pbHostLibcVersion().decode(), "cpus": cpus,
+            "usable_cpus": res["usable_cpus"], "cgroup_cpu_quota": res["cgroup_cpus"] if res["cgroup_cpus"] > 0 else None,
+            "ranks_per_node": res["local_world_size"], "host_threads": res["host_threads"],
+            "gpu_numa_node": res["numa_node"], "gpu_numa_cpus": res["numa_cpus"], "pin_producers": bool(res["pin_producers"]),
+            "host_threads_rule": res["rule"],
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
 
 
@@ -772,6 +922,8 @@ def divert_stdout():
 
 
 def emit(out):
+    if DRY:
+        out["dry_run"] = True
     sys.stdout.flush()
     try:
         import ctypes
@@ -789,7 +941,7 @@ def spawn_ranks(args):
     before this one has made any HIP or torch.cuda call -- and pass its exit code on."""
     import subprocess
     import torch
-    have = torch.cuda.device_count()  # (does not initialise the GPU)
+    have = args.gpus if args.dry_run_device else torch.cuda.device_count()  # (does not initialise the GPU)
     if have < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible\n")
         return 2
@@ -830,14 +982,25 @@ def main():
     ap.add_argument("--no-ensemble-leg", action="store_true")
     ap.add_argument("--prewarm-ms", type=float, default=100.0,
                     help="device time of scratch work before the measured simulation (clock ramp); 0 disables")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="time budget of the cpu_baseline sample")
     ap.add_argument("--force-variant", type=int, default=2, choices=[0, 1, 2, 3],
                     help="force kernel of the arena workload (default 2, the exact kernel = the headline).  3 = the "
                          "opt-in streamlined kernel: for profiling it with tools/profile.sh; the line then says "
                          "`headline: false`")
+    ap.add_argument("--dry-run-device", action="store_true",
+                    help="TEST ONLY (tests/test_bench_multirank.py): no GPU is touched -- gloo process group, the arena "
+                         "replaced by a counter, ensemble members placed for real but never stepped; the line says "
+                         "dry_run: true and none of its numbers mean anything")
+    ap.add_argument("--rendezvous-timeout", type=float, default=120.0,
+                    help="seconds a rank waits for the others at the rendezvous before bench.py exits with code 2")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="producer threads per pipeline of the ensemble end-to-end runs (default: the rank's share of "
+                         "the usable cores, pbHostGetResources)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path")
     args = ap.parse_args()
+    global DRY
+    DRY = args.dry_run_device
     # HIP gives a new stream the least-used of GPU_MAX_HW_QUEUES (default 4) hardware queues.  Next to the streams of
     # PyTorch and RCCL (any run with a process group) the two batches of the configs[3] leg -- one stream each, meant
     # to overlap -- landed on ONE queue and serialised: 1.68 s end to end instead of 0.95 (round 3, --force-dist).
@@ -866,16 +1029,35 @@ def main():
         divert_stdout()
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        assert dist.get_world_size() == world
-        dist.barrier()   # (the communicator and RCCL's kernels are set up here, not inside a measurement's first barrier)
+        # The rendezvous has its own, short deadline: a rank that never arrives (died at start-up, wrong WORLD_SIZE)
+        # must end the run with exit code 2 after --rendezvous-timeout seconds, not hang it for the process group's
+        # collective timeout.  (Port MASTER_PORT + 1: the launcher's own store may sit on MASTER_PORT.)
+        try:
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1, world, rank == 0,
+                                  timeout=datetime.timedelta(seconds=args.rendezvous_timeout), wait_for_workers=True)
+            store.set(f"rank{rank}", "here")
+            store.wait([f"rank{r}" for r in range(world)], datetime.timedelta(seconds=args.rendezvous_timeout))
+            if DRY:
+                dist.init_process_group(backend="gloo", store=store, rank=rank, world_size=world)
+            else:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group(backend="nccl", store=store, rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            assert dist.get_world_size() == world
+            dist.barrier()   # (the communicator and RCCL's kernels are set up here, not inside a measurement's first barrier)
+        except Exception as e:
+            sys.stderr.write(f"bench.py: rank {rank} of {world}: rendezvous failed ({type(e).__name__}: {e})\n")
+            sys.stderr.flush()
+            os._exit(2)
 
     import particlerobotsimulations_amd as pb
 
-    if dist is None:
+    if DRY:
+        pb = _DryPb
+    elif dist is None:
         pb.legacy.cudaInit(0, None)  # otherwise torch.cuda.set_device above already chose this rank's GPU
 
     if args.workload != "arena":
@@ -899,7 +1081,7 @@ def main():
     def barrier():
         sim.synchronize()
         if dist is not None:
-            torch.cuda.synchronize()
+            dev_sync(torch)
             dist.barrier()
 
     prewarm = warm.run()
@@ -916,7 +1098,7 @@ def main():
         dist.barrier()
         warm.synchronize()
         sim.synchronize()
-        torch.cuda.synchronize()
+        dev_sync(torch)
     else:
         barrier()
     s0 = sim.stats()
@@ -934,12 +1116,12 @@ def main():
         long_steps, long_ms = sim.step_timed(min(int(LONG_MS / max(dev_ms / done, 1e-6)) + 1, 400000))
 
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device=dist_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
         # the only data exchange of an ensemble: per-arena summaries (time, COMx, COMy), gathered
         cx, cy = sim.centroid()
-        mine = torch.tensor([sim.time, cx, cy], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([sim.time, cx, cy], dtype=torch.float64, device=dist_device())
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         summaries = [[float(x) for x in v.tolist()] for v in allv]

@@ -54,13 +54,17 @@ unsigned pbEnsembleNumBots(void *ensemble);
  * (pbEnsemblePipelineGetState).  Returns the timesteps per member, -1 on error. */
 typedef struct pbEnsembleTimings {
   double wall_s;            /* the whole Run call: placement still outstanding + upload + steps + read-backs */
-  double placement_cpu_s;   /* CPU-seconds the producer threads spent building members (sum over threads) */
+  double placement_cpu_s;   /* CPU-seconds (CLOCK_THREAD_CPUTIME_ID) the producer threads spent building members, summed */
   double placement_wait_s;  /* time the device-driving thread waited for members to be built (the device idles) */
   double upload_s;          /* pbSimCreateBatch + state upload of all sub-batches */
   double device_s;          /* stepping + summary rows (+ final-state read-back) of all sub-batches */
   int sub_batches;
   int sub_batch;            /* members per sub-batch as used */
   int host_threads;         /* producer threads as used */
+  int pinned;               /* 1: the producers ran pinned to the cores of the GPU's NUMA node */
+  int numa_node;            /* that node, -1 unknown */
+  double placement_thread_wall_s; /* wall seconds the producers spent building members (sum over threads): exceeds
+                               placement_cpu_s when the threads did not get a core each (oversubscription, quota) */
 } pbEnsembleTimings;
 void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
                                int nmembers, int sub_batch, int host_threads, int keep_final_states);
@@ -78,12 +82,45 @@ void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *com
 long pbEnsemblePipelineRun(void *pipeline, long max_steps, float *out, int max_rows, int *rows,
                            pbEnsembleTimings *timings);
 void pbEnsemblePipelineDestroy(void *pipeline);
+/* producer threads this pipeline started (pbHostResources.host_threads minus one for the device-driving thread when
+ * host_threads <= 0 was asked for, at most one per member) */
+int pbEnsemblePipelineHostThreads(void *pipeline);
 unsigned pbEnsemblePipelineNumBots(void *pipeline);
 int pbEnsemblePipelineGetState(void *pipeline, int member, float *pos, float *vel, float *rad);
 /* The consumer side without a device (CPU tests): takes the sub-batches in order as Run does, records a checksum
  * of every member's placed state instead of stepping it, dwells dwell_ms per sub-batch; *max_ahead = the most
  * members ever claimed by producers beyond the consumed ones (bounded by 3 sub-batches). */
 int pbEnsemblePipelineDryRun(void *pipeline, int dwell_ms, unsigned long long *checksums, int *max_ahead);
+
+/* ---- host resources of a rank ----------------------------------------------------------------------------------
+ * Placement is host work and a node's ranks share its cores, so the producer pool of a rank is sized from what the
+ * process may REALLY use: min(hardware threads, scheduler affinity, cgroup CPU quota -- cpu.max of the process's
+ * cgroup and its ancestors (v2), cpu.cfs_quota_us / cpu.cfs_period_us (v1)) divided by the ranks of the node
+ * (LOCAL_WORLD_SIZE / OMPI_COMM_WORLD_LOCAL_SIZE / SLURM_NTASKS_PER_NODE), at most 128.  PB_HOST_THREADS or the
+ * host_threads argument override the share.  When the rank's GPU reports a NUMA node
+ * (/sys/bus/pci/devices/<bus id>/numa_node >= 0) the producer threads are pinned to that node's cores
+ * (local_cpulist, intersected with the affinity mask; PB_PIN_PRODUCERS=0 disables): members are placed in memory
+ * next to the GPU that will receive them and the pools of different ranks do not migrate across sockets.
+ * The reference has nothing of this (one device, one thread: main.cpp:350).
+ * Test hooks: PB_CGROUP_ROOT (default /sys/fs/cgroup), PB_SYSFS_ROOT (default /sys), PB_PROC_SELF_CGROUP. */
+typedef struct pbHostResources {
+  int hardware_threads;  /* std::thread::hardware_concurrency() */
+  int affinity_cpus;     /* CPU_COUNT(sched_getaffinity) */
+  double cgroup_cpus;    /* quota / period of the tightest cgroup level; <= 0: unlimited */
+  int usable_cpus;       /* min of the three, >= 1 */
+  int local_world_size;  /* ranks sharing this node, 1 if no launcher variable is set */
+  int host_threads;      /* this rank's share (what pbEnsemblePipelineCreate(host_threads <= 0) starts from) */
+  int device;            /* the calling thread's HIP device, -1: none */
+  int numa_node;         /* of that device, -1: unknown / not a NUMA machine */
+  int numa_cpus;         /* cores of that node this process may run on, 0: unknown */
+  int pin_producers;     /* 1: producer threads are pinned to those cores */
+  char pci_bus_id[32];
+  char rule[200];        /* the sentence bench.py prints: how host_threads came about */
+} pbHostResources;
+int pbHostGetResources(pbHostResources *out);
+/* Parses a sysfs cpulist ("0-31,64-95") restricted to the affinity mask; returns the number of cores and, if
+ * `cpus` is given, the first `cap` of them. */
+int pbHostParseCpuList(const char *text, int *cpus, int cap);
 
 /* Number of members rank `rank` of `world` runs (members rank, rank + world, ...); block size per
  * rank in the gather = pbEnsembleShard(nmembers, 0, world). */

@@ -153,6 +153,9 @@ const char *pbGetLastErrorString(void);
  * that calls pbEnsemblePipelineRun. */
 int pbGetDevice(int *device);
 int pbSetDevice(int device);
+/* "0000:c1:00.0"-style PCI address of a device (cap >= 13): the key under /sys/bus/pci/devices whose numa_node /
+ * local_cpulist say which host cores sit next to the GPU (pbHostGetResources, include/particlebot_ensemble.h). */
+int pbDevicePciBusId(int device, char *out, int cap);
 
 /* Creates a simulation of params->nCells bots on the current device.  The parameter block is
  * copied (obstacle arrays included, at most PB_MAX_OBSTACLES each).  wallHalf <= 0 selects the

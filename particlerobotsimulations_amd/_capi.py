@@ -116,6 +116,7 @@ SYMBOLS = {
     "sortParticlebots": (None, [_VP, _VP, _U]),
     "pbGetLastErrorString": (C.c_char_p, []),
     "pbGetDevice": (_I, [C.POINTER(_I)]),
+    "pbDevicePciBusId": (_I, [_I, C.c_char_p, _I]),
     "pbSetDevice": (_I, [_I]),
     "pbSimCreate": (_I, [C.POINTER(_VP), C.POINTER(SimParams), _F]),
     "pbSimDestroy": (None, [_VP]),

@@ -1,6 +1,7 @@
 // pb_capi.cpp -- C wrappers around the C++ host side (class Particlebot + .cfg loader) so that
 // scripts and tests can drive it through ctypes.  Exported from libparticlebot_host.so.
 #include <gnu/libc-version.h>
+#include <pthread.h>
 #include <sched.h>
 #include <sys/stat.h>
 
@@ -13,6 +14,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -372,20 +374,181 @@ bool buildMember(Member &m, const char *cfg_path, const char *common_overrides, 
   return true;
 }
 
-// host threads for placement: all cores, shared between the ranks of a node (one process per GPU)
-unsigned hostThreads(int wanted) {
-  unsigned nthreads = std::thread::hardware_concurrency();
-  for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE"})
-    if (const char *v = getenv(name)) {
-      if (atoi(v) > 1) nthreads = std::max(1u, nthreads / (unsigned)atoi(v));
-      break;
+// ---- host resources of a rank (include/particlebot_ensemble.h "host resources") ---------------------------------
+std::string envOr(const char *name, const char *fallback) {
+  const char *v = getenv(name);
+  return v && v[0] ? v : fallback;
+}
+
+bool readLine(const std::string &path, std::string &out) {
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) return false;
+  char buf[4096];
+  const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+  fclose(f);
+  if (!ok) return false;
+  out = buf;
+  while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
+  return true;
+}
+
+// CPUs the cgroup CPU controller grants: the tightest quota / period on the way from the process's own cgroup up to
+// the mount point (v2: cpu.max "quota period" or "max period"; v1: cpu.cfs_quota_us, -1 = unlimited).  <= 0: unlimited.
+double cgroupCpus() {
+  const std::string root = envOr("PB_CGROUP_ROOT", "/sys/fs/cgroup");
+  double best = 0.0;
+  auto take = [&](double cpus) {
+    if (cpus > 0.0 && (best <= 0.0 || cpus < best)) best = cpus;
+  };
+  // the process's cgroup path: "0::/a/b" (v2) -- inside a container's cgroup namespace this is "/"
+  std::string rel = "/";
+  if (FILE *f = fopen(envOr("PB_PROC_SELF_CGROUP", "/proc/self/cgroup").c_str(), "r")) {
+    char buf[4096];
+    while (fgets(buf, sizeof buf, f)) {
+      if (strncmp(buf, "0::", 3) == 0) {
+        rel = buf + 3;
+        while (!rel.empty() && (rel.back() == '\n' || rel.back() == ' ')) rel.pop_back();
+        break;
+      }
     }
-  if (const char *v = getenv("PB_HOST_THREADS")) nthreads = (unsigned)atoi(v);
-  if (wanted > 0) nthreads = (unsigned)wanted;
+    fclose(f);
+  }
+  if (rel.empty() || rel[0] != '/' || rel.find("..") != std::string::npos) rel = "/";
+  for (std::string dir = rel;;) {
+    std::string line;
+    if (readLine(root + dir + (dir.back() == '/' ? "" : "/") + "cpu.max", line)) {
+      char q[64] = {0};
+      double period = 0.0;
+      if (sscanf(line.c_str(), "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) take(atof(q) / period);
+    }
+    if (dir == "/" || dir.empty()) break;
+    const size_t cut = dir.find_last_of('/');
+    dir = cut == 0 ? "/" : dir.substr(0, cut);
+  }
+  std::string q, per;  // cgroup v1
+  if (readLine(root + "/cpu/cpu.cfs_quota_us", q) && readLine(root + "/cpu/cpu.cfs_period_us", per) && atof(q.c_str()) > 0 &&
+      atof(per.c_str()) > 0)
+    take(atof(q.c_str()) / atof(per.c_str()));
+  return best;
+}
+
+int affinityCpus(cpu_set_t *setOut) {
   cpu_set_t set;
-  if (sched_getaffinity(0, sizeof set, &set) == 0 && wanted <= 0)
-    nthreads = std::min<unsigned>(nthreads, (unsigned)CPU_COUNT(&set));
-  return std::max(1u, std::min(nthreads, 128u));
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) != 0) return 0;
+  if (setOut) *setOut = set;
+  return CPU_COUNT(&set);
+}
+
+int localWorldSize() {
+  for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE"})
+    if (const char *v = getenv(name)) return std::max(1, atoi(v));
+  return 1;
+}
+
+// "0-3,8,10-11" -> the listed cores that are also in the affinity mask
+std::vector<int> parseCpuList(const char *text) {
+  std::vector<int> cpus;
+  cpu_set_t aff;
+  const bool haveAff = affinityCpus(&aff) > 0;
+  for (const char *p = text; p && *p;) {
+    while (*p == ',' || *p == ' ' || *p == '\n') p++;
+    if (!*p) break;
+    char *end = nullptr;
+    const long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    p = end;
+    if (*p == '-') {
+      b = strtol(p + 1, &end, 10);
+      if (end == p + 1) break;
+      p = end;
+    }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+      if (c >= 0 && (!haveAff || CPU_ISSET((int)c, &aff))) cpus.push_back((int)c);
+  }
+  return cpus;
+}
+
+// the cores next to a device: /sys/bus/pci/devices/<bus id>/numa_node (>= 0 on a NUMA machine) + local_cpulist
+int numaOfDevice(int device, std::string &busId, std::vector<int> &cpus) {
+  cpus.clear();
+  busId.clear();
+  if (device < 0) return -1;
+  char id[32] = {0};
+  if (const char *fake = getenv("PB_FAKE_PCI_BUS_ID")) {  // CPU tests: no device to ask
+    snprintf(id, sizeof id, "%s", fake);
+  } else if (pbDevicePciBusId(device, id, (int)sizeof id) != PB_OK) {
+    return -1;
+  }
+  for (char *c = id; *c; c++) *c = (char)tolower(*c);
+  busId = id;
+  const std::string dir = envOr("PB_SYSFS_ROOT", "/sys") + "/bus/pci/devices/" + busId;
+  std::string node, list;
+  if (!readLine(dir + "/numa_node", node)) return -1;
+  const int n = atoi(node.c_str());
+  if (n < 0) return -1;
+  if (readLine(dir + "/local_cpulist", list)) cpus = parseCpuList(list.c_str());
+  return n;
+}
+
+void describeResources(pbHostResources &r, int wanted) {
+  memset(&r, 0, sizeof r);
+  r.hardware_threads = (int)std::thread::hardware_concurrency();
+  r.affinity_cpus = affinityCpus(nullptr);
+  r.cgroup_cpus = cgroupCpus();
+  int usable = r.hardware_threads > 0 ? r.hardware_threads : 1;
+  if (r.affinity_cpus > 0) usable = std::min(usable, r.affinity_cpus);
+  if (r.cgroup_cpus > 0.0) usable = std::min(usable, std::max(1, (int)std::floor(r.cgroup_cpus + 1e-9)));
+  r.usable_cpus = std::max(1, usable);
+  r.local_world_size = localWorldSize();
+  int share = std::max(1, r.usable_cpus / r.local_world_size);
+  const char *why = "usable cores / ranks of the node";
+  if (const char *v = getenv("PB_HOST_THREADS")) {
+    if (atoi(v) > 0) {
+      share = atoi(v);
+      why = "PB_HOST_THREADS";
+    }
+  }
+  if (wanted > 0) {
+    share = wanted;
+    why = "host_threads argument";
+  }
+  r.host_threads = std::max(1, std::min(share, 128));
+  r.device = -1;
+  r.numa_node = -1;
+  int dev = -1;
+  if (getenv("PB_FAKE_PCI_BUS_ID")) dev = 0;
+  else if (pbGetDevice(&dev) != PB_OK) dev = -1;
+  r.device = dev;
+  std::string bus;
+  std::vector<int> cpus;
+  r.numa_node = numaOfDevice(dev, bus, cpus);
+  snprintf(r.pci_bus_id, sizeof r.pci_bus_id, "%s", bus.c_str());
+  r.numa_cpus = (int)cpus.size();
+  const char *pin = getenv("PB_PIN_PRODUCERS");
+  r.pin_producers = (r.numa_node >= 0 && r.numa_cpus > 0 && !(pin && pin[0] == '0')) ? 1 : 0;
+  char quota[48];
+  if (r.cgroup_cpus > 0.0) snprintf(quota, sizeof quota, "%.2f", r.cgroup_cpus);
+  else snprintf(quota, sizeof quota, "none");
+  snprintf(r.rule, sizeof r.rule,
+           "%d producer threads (%s): min(hardware %d, affinity %d, cgroup quota %s) = %d usable / %d rank(s) per node; "
+           "%s",
+           r.host_threads, why, r.hardware_threads, r.affinity_cpus, quota, r.usable_cpus, r.local_world_size,
+           r.pin_producers ? "pinned to the GPU's NUMA node" : "not pinned (no NUMA node reported for the device)");
+}
+
+// host threads for placement: this rank's share of the cores the process may really use
+unsigned hostThreads(int wanted) {
+  pbHostResources r;
+  describeResources(r, wanted);
+  return (unsigned)r.host_threads;
+}
+
+double threadCpuSeconds() {
+  timespec ts;
+  if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) != 0) return 0.0;
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
 // ---- ensemble checkpoints (pbEnsemblePipelineSetCheckpoint) ------------------------------------------------------
@@ -673,7 +836,9 @@ struct Pipeline {
   std::vector<std::vector<float>> finalPos, finalVel, finalRad;
   unsigned nbots = 0;
   pbEnsembleTimings tm{};
-  std::vector<double> cpuSeconds;  // per producer thread
+  std::vector<double> cpuSeconds, wallSeconds;  // per producer thread: CPU time and wall time spent building members
+  std::vector<int> pinCpus;                     // cores of the GPU's NUMA node (empty: producers are not pinned)
+  int numaNode = -1;
   int device = -1;      // the creating thread's HIP device: Run may be called from another thread (which starts on 0)
   std::string ckptDir;  // checkpoints (pbEnsemblePipelineSetCheckpoint); empty: none
   bool resume = false;
@@ -689,7 +854,7 @@ struct Pipeline {
         if (stop || failed || nextToBuild >= nmembers) return;
         k = nextToBuild++;
       }
-      const double t0 = nowSeconds();
+      const double t0 = nowSeconds(), c0 = threadCpuSeconds();
       Member *m = new Member();
       const char *cp = haveCfg ? cfgPath.c_str() : nullptr, *co = common.empty() ? nullptr : common.c_str();
       bool ok = true, restored = false;
@@ -711,7 +876,8 @@ struct Pipeline {
         m = new Member();
         ok = buildMember(*m, cp, co, over[k].c_str());
       }
-      cpuSeconds[tid] += nowSeconds() - t0;
+      cpuSeconds[tid] += threadCpuSeconds() - c0;
+      wallSeconds[tid] += nowSeconds() - t0;
       std::lock_guard<std::mutex> lock(mu);
       if (!ok) {
         delete m;
@@ -726,7 +892,17 @@ struct Pipeline {
   }
   void start() {
     cpuSeconds.assign(threads, 0.0);
+    wallSeconds.assign(threads, 0.0);
     for (int t = 0; t < threads; t++) pool.emplace_back(&Pipeline::producer, this, t);
+    if (!pinCpus.empty()) {
+      // the whole pool on the cores next to the GPU (the scheduler spreads the threads inside the set)
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      for (int c : pinCpus) CPU_SET(c, &set);
+      bool ok = true;
+      for (auto &th : pool) ok = pthread_setaffinity_np(th.native_handle(), sizeof set, &set) == 0 && ok;
+      tm.pinned = ok ? 1 : 0;
+    }
   }
   void shutdown() {
     {
@@ -815,7 +991,14 @@ void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *com
   for (int k = 0; k < nmembers; k++) p->over.emplace_back(member_overrides && member_overrides[k] ? member_overrides[k] : "");
   p->nmembers = nmembers;
   // the calling thread drives the device: leave it a core when there are several
-  const unsigned avail = hostThreads(host_threads);
+  pbHostResources res;
+  describeResources(res, host_threads);
+  const unsigned avail = (unsigned)res.host_threads;
+  if (res.pin_producers) {
+    std::string bus;
+    p->numaNode = numaOfDevice(res.device, bus, p->pinCpus);
+  }
+  p->tm.numa_node = res.numa_node;
   p->threads = (int)std::max(1u, std::min<unsigned>(host_threads > 0 ? avail : (avail > 1 ? avail - 1 : 1), (unsigned)nmembers));
   // sub_batch -1: one placement round of the producer pool per sub-batch (every producer places one member, so the
   // device never waits for a second round: with 31 producers a 32-member sub-batch is ready after 3.0 s, a
@@ -882,6 +1065,8 @@ void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_override
 }
 
 void pbEnsemblePipelineDestroy(void *pv) { delete (Pipeline *)pv; }
+
+int pbEnsemblePipelineHostThreads(void *pv) { return pv ? ((Pipeline *)pv)->threads : 0; }
 
 long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, int *rows, pbEnsembleTimings *timings) {
   Pipeline *p = (Pipeline *)pv;
@@ -986,8 +1171,9 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
     p->tm.sub_batches++;
   }  // (~Ensemble frees the sub-batch's device memory and its members)
   p->tm.wall_s = nowSeconds() - t0;
-  p->tm.placement_cpu_s = 0.0;
+  p->tm.placement_cpu_s = p->tm.placement_thread_wall_s = 0.0;
   for (double c : p->cpuSeconds) p->tm.placement_cpu_s += c;
+  for (double c : p->wallSeconds) p->tm.placement_thread_wall_s += c;
   if (rows) *rows = nrowsAll;
   if (timings) *timings = p->tm;
   return steps;
@@ -1024,6 +1210,7 @@ int pbEnsemblePipelineDryRun(void *pv, int dwell_ms, unsigned long long *checksu
     for (int k = 0; k < count; k++) {
       const Particlebot *b = mine[k]->bot;
       const size_t n = b->getParams().nCells;
+      p->nbots = (unsigned)n;
       unsigned long long h = 1469598103934665603ull;
       auto mix = [&](const void *data, size_t bytes) {
         const unsigned char *c = (const unsigned char *)data;
@@ -1058,6 +1245,18 @@ int pbEnsemblePipelineGetState(void *pv, int member, float *pos, float *vel, flo
 }
 
 int pbEnsembleSynchronize(void *ev) { return pbSimSynchronize(((Ensemble *)ev)->sim); }
+
+int pbHostGetResources(pbHostResources *out) {
+  if (!out) return 1;
+  describeResources(*out, 0);
+  return 0;
+}
+
+int pbHostParseCpuList(const char *text, int *cpus, int cap) {
+  const std::vector<int> v = parseCpuList(text);
+  for (int i = 0; cpus && i < cap && i < (int)v.size(); i++) cpus[i] = v[i];
+  return (int)v.size();
+}
 
 int pbEnsembleShard(int nmembers, int rank, int world) {
   if (nmembers < 0 || world < 1 || rank < 0 || rank >= world) return 0;

@@ -1078,6 +1078,12 @@ int pbSetDevice(int device) {
   return PB_OK;
 }
 
+int pbDevicePciBusId(int device, char *out, int cap) {
+  if (!out || cap < 13) return PB_ERR_ARG;
+  PB_TRY(hipDeviceGetPCIBusId(out, cap, device));
+  return PB_OK;
+}
+
 int pbSimSetMinDistanceMode(pbSim *S, int mode) {
   if (!S || mode < 0 || mode > 1) return PB_ERR_ARG;
   S->minDistanceMode = mode;

@@ -149,7 +149,19 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
     float coef = pbFarCoefS(A, gap);
     // gap < near2: one of the two near bands or contact (gap < 0) -- rare: a wave-uniform branch on one ballot
     if (__builtin_amdgcn_ballot_w64(gap < near2) != 0ull) {
-      const bool contact = gap < 0.0f;                             // dist < reach
+      bool contact = gap < 0.0f;                                   // dist < reach
+      // Round 4: the contact decision is the one discontinuity of the pair force (2.5 N of attraction floor against
+      // a spring that starts at 0), and a placed blob is full of pairs that touch EXACTLY (dist == reach to the last
+      // bit; held bots keep them so for hundreds of steps).  dist from v_rsq_f32 is 1-2 ulp off, which decided those
+      // pairs at random: 5-8 x the flips of an FMA-contracted build of the reference's own arithmetic
+      // (tests/test_gpu_fma_bracket.py).  Within ~7 ulp of the threshold the decision is therefore taken as the
+      // reference takes it -- IEEE root of the uncontracted dot product against the sum of radii (impl.cuh:551-555);
+      // a wave-uniform branch inside the rare block, taken in well under 1 % of the trips.
+      if (__builtin_amdgcn_ballot_w64(fabsf(gap) < 1e-7f) != 0ull) {
+        const float rr = rx * rx, d2e = rr + ry * ry;
+        const bool exact = sqrtf(d2e) < me.z + q.z;
+        contact = fabsf(gap) < 1e-7f ? exact : contact;
+      }
       const float K = PAYLOAD ? pbBandSlope(A) : slope0;
       const float band = gap < near1 ? fmin_attr : __builtin_fmaf(K, gap - near1, fmin_attr);
       coef = gap < near2 ? band : coef;

@@ -117,7 +117,32 @@ class Timings(C.Structure):
     """pbEnsembleTimings (include/particlebot_ensemble.h)."""
     _fields_ = [("wall_s", C.c_double), ("placement_cpu_s", C.c_double), ("placement_wait_s", C.c_double),
                 ("upload_s", C.c_double), ("device_s", C.c_double), ("sub_batches", C.c_int), ("sub_batch", C.c_int),
-                ("host_threads", C.c_int)]
+                ("host_threads", C.c_int), ("pinned", C.c_int), ("numa_node", C.c_int),
+                ("placement_thread_wall_s", C.c_double)]
+
+
+class HostResources(C.Structure):
+    """pbHostResources (include/particlebot_ensemble.h)."""
+    _fields_ = [("hardware_threads", C.c_int), ("affinity_cpus", C.c_int), ("cgroup_cpus", C.c_double),
+                ("usable_cpus", C.c_int), ("local_world_size", C.c_int), ("host_threads", C.c_int),
+                ("device", C.c_int), ("numa_node", C.c_int), ("numa_cpus", C.c_int), ("pin_producers", C.c_int),
+                ("pci_bus_id", C.c_char * 32), ("rule", C.c_char * 200)]
+
+
+def host_resources():
+    """What a rank's producer pool is sized from (pbHostGetResources): hardware threads, scheduler affinity, the
+    cgroup CPU quota, the ranks sharing the node, the GPU's NUMA node."""
+    from . import host
+    L = host.lib()
+    L.pbHostGetResources.argtypes = [C.POINTER(HostResources)]
+    r = HostResources()
+    if L.pbHostGetResources(C.byref(r)) != 0:
+        raise RuntimeError("pbHostGetResources failed")
+    out = {}
+    for k, _ in HostResources._fields_:
+        v = getattr(r, k)
+        out[k] = v.decode() if isinstance(v, bytes) else v
+    return out
 
 
 def _pipeline_lib():
@@ -178,6 +203,27 @@ class PipelinedEnsemble:
         self.timings = {k: getattr(tm, k) for k, _ in Timings._fields_}
         self.n = int(self._L.pbEnsemblePipelineNumBots(self._h))
         return int(steps)
+
+    def run_dry(self, max_steps, nrows=3):
+        """CPU-only stand-in for run() (bench.py --dry-run-device, tests): the members are placed for real and taken
+        by the pipeline's dry-run consumer; every member then gets `nrows` summary rows made from the checksum of
+        its placed state (so a row identifies its member whatever rank placed it), no timestep runs."""
+        sums, _ahead = self.dry_run()
+        self._rows = C.c_int(nrows)
+        for k in range(self.m):
+            v = [float((int(sums[k]) >> s) & 0xFFFF) / 65536.0 for s in (0, 16, 32)]
+            for r in range(nrows):
+                self.out[k, r] = (r * 6.0, v[0], v[1], v[2])
+        self.n = int(self._L.pbEnsemblePipelineNumBots(self._h))
+        self.timings = {k: 0 for k, _ in Timings._fields_}
+        self.timings.update(host_threads=self.host_threads, sub_batch=0, dry_run=True)
+        return int(max_steps)
+
+    @property
+    def host_threads(self):
+        """producer threads this pipeline started"""
+        self._L.pbEnsemblePipelineHostThreads.argtypes = [C.c_void_p]
+        return int(self._L.pbEnsemblePipelineHostThreads(self._h)) if self._h else 0
 
     def dry_run(self, dwell_ms=0):
         """CPU-only: the pipeline's consumer without a device.  Returns (checksums[m] of the placed members,

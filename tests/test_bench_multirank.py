@@ -1,0 +1,116 @@
+"""bench.py's N > 1 path, run for real with two ranks before the driver's SCALE run does it (VERDICT round 3:
+"has only ever executed with world size 1").  No GPU here: `--dry-run-device` puts gloo under the same
+choreography -- spawn_ranks, the rendezvous, the opening/closing barriers, the MAX all-reduce of the wall time, the
+gather of the members' summary rows, ONE JSON line from rank 0 on stdout -- and replaces the device by stand-ins
+(the arena by a counter; ensemble members are placed for real by the producer pool and their rows made from the
+checksum of the placed state, so a gathered row identifies its member).  The numbers of a dry-run line mean nothing;
+its structure is what the driver will parse."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run_bench(*args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, BENCH, *args], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=timeout)
+    return p
+
+
+def one_json_line(p):
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must carry ONE line, got {len(lines)}: {[l[:80] for l in lines]}"
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module")
+def two_rank_ensemble():
+    return one_json_line(run_bench("--gpus", "2", "--workload", "ensemble4", "--e2e-steps", "200", "--steps", "50",
+                                   "--dry-run-device"))
+
+
+def test_two_rank_ensemble_line(two_rank_ensemble):
+    d = two_rank_ensemble
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 50
+    assert d["metric"].startswith("particle-steps/sec at 10^6 bots") and d["unit"] == "particle-steps/s"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32"
+    cfg = d["config"]
+    # member k -> rank k mod 2; 32 members per GPU and per .cfg, two .cfgs
+    assert cfg["members_per_rank"] == [64, 64] and cfg["members_total"] == 128 and cfg["bots_per_member"] == [500, 201]
+    assert "world size 2" in cfg["parallelism"]
+    assert d["summary_rows_gathered"] == [[64, 3, 4], [64, 3, 4]]
+    e2e = d["end_to_end"]
+    assert e2e["n_gpus"] == 2 and e2e["members_total"] == 128 and e2e["rows_gathered"] == [[64, 3, 4], [64, 3, 4]]
+    assert e2e["steps_per_member"] == 200
+    # each rank sized its producer pool from ITS share of the host (LOCAL_WORLD_SIZE = 2 under the launcher)
+    assert d["host"]["ranks_per_node"] == 2 and d["host"]["host_threads"] == max(1, d["host"]["usable_cpus"] // 2)
+
+
+def test_gather_puts_every_member_in_its_place(two_rank_ensemble):
+    """The same 64 members per .cfg on ONE rank (no process group): the rows rank 0 assembled from two ranks are
+    the one-rank rows, member for member (a row is a function of the member's placed state)."""
+    one = one_json_line(run_bench("--gpus", "1", "--workload", "ensemble4", "--members-per-gpu", "64", "--e2e-steps", "200",
+                                  "--steps", "50", "--dry-run-device"))
+    assert one["n_gpus"] == 1 and one["config"]["members_per_rank"] == [128]
+    a = np.array(two_rank_ensemble["end_to_end"]["last_rows_time_comx_comy_dist"])
+    b = np.array(one["end_to_end"]["last_rows_time_comx_comy_dist"])
+    assert a.shape == b.shape == (2, 4, 4) and np.array_equal(a, b)
+    a = np.array(two_rank_ensemble["summaries_last_row_time_comx_comy_dist"])
+    b = np.array(one["summaries_last_row_time_comx_comy_dist"])
+    assert np.array_equal(a, b) and len({tuple(r) for r in a.reshape(-1, 4)}) == 8  # eight different members
+
+
+def test_two_rank_arena_line():
+    d = one_json_line(run_bench("--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run-device", "--e2e-steps", "100"))
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["scaling"] == "weak" and d["config"]["bots_per_gpu"] == 1_000_000
+    assert "2 independent arenas" in d["config"]["parallelism"]
+    assert len(d["summaries_time_comx_comy"]) == 2          # one summary per rank, gathered
+    assert {"roofline", "ensemble_leg", "host"} <= set(d)
+    leg = d["ensemble_leg"]
+    assert leg["n_gpus"] == 2 and leg["config"]["members_per_rank"] == [64, 64]
+    assert leg["strong_end_to_end"]["members_total"] == 512 and leg["strong_end_to_end"]["scaling"] == "strong"
+    # rank-0-only legs stay out of a multi-rank line
+    assert "cpu_baseline" not in d and "large_arena" not in d and "streamlined" not in d
+
+
+def test_launcher_started_ranks_and_strong_form():
+    """The driver's own form: `python -m torch.distributed.run ... bench.py --gpus 2`; strong scaling by --members-total."""
+    e = dict(os.environ)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), BENCH, "--gpus", "2", "--workload", "ensemble4",
+           "--members-total", "10", "--e2e-steps", "50", "--steps", "20", "--dry-run-device"]
+    p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    d = one_json_line(p)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["members_per_rank"] == [10, 10]
+    assert d["end_to_end"]["rows_gathered"] == [[10, 3, 4], [10, 3, 4]]
+
+
+def test_wrong_world_size_is_refused():
+    p = run_bench("--gpus", "2", "--dry-run-device", env={"WORLD_SIZE": "3", "RANK": "0"})
+    assert p.returncode == 2 and "WORLD_SIZE=3" in p.stderr
+
+
+def test_a_rank_that_never_arrives_ends_the_run_with_code_2():
+    """Rank 0 of a two-rank job whose rank 1 never starts: the rendezvous deadline (--rendezvous-timeout) ends the run
+    with exit code 2 and a message instead of hanging."""
+    port = str(29900 + os.getpid() % 90)
+    t0 = time.time()
+    p = run_bench("--gpus", "2", "--dry-run-device", "--rendezvous-timeout", "3",
+                  env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port},
+                  timeout=120)
+    assert p.returncode == 2, (p.returncode, p.stderr[-2000:])
+    assert "rendezvous failed" in p.stderr and time.time() - t0 < 60
+    assert p.stdout.strip() == ""

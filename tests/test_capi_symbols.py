@@ -103,12 +103,13 @@ def test_ensemble_header_symbols_are_exported_by_the_host_library():
     from particlerobotsimulations_amd import host
     text = open(os.path.join(ROOT, "include", "particlebot_ensemble.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = {m.group(1) for m in re.finditer(r"\b(pbEnsemble\w+)\s*\(", text)}
+    names = {m.group(1) for m in re.finditer(r"\b(pb(?:Ensemble|Host)\w+)\s*\(", text)}
     assert names == {"pbEnsembleCreate", "pbEnsembleDestroy", "pbEnsembleRun", "pbEnsembleRunSteps",
                      "pbEnsembleSynchronize", "pbEnsembleGetState", "pbEnsembleNumBots", "pbEnsembleShard",
                      "pbEnsembleAssemble", "pbEnsemblePipelineCreate", "pbEnsemblePipelineCreateCheckpointed",
                      "pbEnsemblePipelineRun", "pbEnsemblePipelineDestroy", "pbEnsemblePipelineNumBots",
-                     "pbEnsemblePipelineGetState", "pbEnsemblePipelineDryRun"}
+                     "pbEnsemblePipelineGetState", "pbEnsemblePipelineDryRun", "pbEnsemblePipelineHostThreads",
+                     "pbHostGetResources", "pbHostParseCpuList"}
     L = host.lib()
     for n in names:
         assert hasattr(L, n), n
