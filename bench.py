@@ -339,6 +339,7 @@ def streamlined_leg(pb, n, pitch, steps, warmup, warm=None):
                                   "(tests/test_gpu_baseline_configs.py::test_bench_headline_workload_matches_oracle); "
                                   "oracle-side flip statistics at 10^6 bots and on blobs: tests/test_gpu_streamlined.py "
                                   "(bench.py may use oracle/ only in cpu_baseline)",
+                       "vs_fma_bracket": fma_bracket_summary(),
                        "window_steps": 10, "max_abs_dpos": float(d.max()),
                        "median_abs_dpos": float(np.median(d)), "bots_beyond_1e-5_relative": int((rel > 1e-5).sum()),
                        "com_abs_dev": com},
@@ -347,6 +348,41 @@ def streamlined_leg(pb, n, pitch, steps, warmup, warm=None):
                     "relative over 10-step windows by tests/test_gpu_streamlined.py.  `value` of the line is the exact "
                     "kernel."})
     return out
+
+
+def fma_bracket_summary():
+    """The streamlined kernel against the FMA / __powf bracket of the reference's own arithmetic, from the committed
+    record of tests/test_gpu_fma_bracket.py on MI355X (tests/golden/fma_bracket/hip_streamlined.json: teacher-forced
+    10-step windows of every BASELINE config, the oracle as teacher, oracle/libpb_oracle_fma[_powf].so as the
+    bracket).  bench.py itself runs no oracle code outside cpu_baseline; None if the record is absent."""
+    path = os.path.join(ROOT, "tests", "golden", "fma_bracket", "hip_streamlined.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None
+    tot = {}
+    for case in rec["cases"].values():
+        for cand, recs in case["candidates"].items():
+            t = tot.setdefault(cand, {"flips": 0, "bot_windows": 0, "p99_worst": 0.0, "com_rel_worst": 0.0})
+            for r in recs:
+                w = r["window"]
+                t["flips"] += w["flips"]
+                t["bot_windows"] += case["bots"]
+                t["p99_worst"] = max(t["p99_worst"], w["p99"])
+                if case["case"] != "cfg3_arena_crop_10k":   # centred on the origin: |COM| ~ 0, relative figure meaningless
+                    t["com_rel_worst"] = max(t["com_rel_worst"], w["com_rel"])
+    rate = lambda c: tot[c]["flips"] / max(tot[c]["bot_windows"], 1)
+    bracket = max(rate("fma"), rate("fma_powf"))
+    return {"flip_rate_streamlined": rate("hip_streamlined"), "flip_rate_fma": rate("fma"),
+            "flip_rate_fma_powf": rate("fma_powf"),
+            "ratio": (rate("hip_streamlined") / bracket) if bracket > 0 else None,
+            "flips_streamlined": tot["hip_streamlined"]["flips"], "flips_fma": tot["fma"]["flips"],
+            "bot_windows": tot["hip_streamlined"]["bot_windows"],
+            "p99_worst": {c: tot[c]["p99_worst"] for c in tot}, "com_rel_worst": {c: tot[c]["com_rel_worst"] for c in tot},
+            "source": "tests/golden/fma_bracket/hip_streamlined.json (tests/test_gpu_fma_bracket.py on MI355X)",
+            "note": "flip = a bot more than 1e-5 relative from the oracle after a teacher-forced 10-step window; the "
+                    "bracket is the oracle's own source with its kernels FMA-contracted (what nvcc -fmad=true does "
+                    "to the reference) and with exp2f(2*log2f(x)) for __powf: the reference's build-to-build spread"}
 
 
 def both_sums_leg(pb, n, pitch, steps, warmup, warm=None):

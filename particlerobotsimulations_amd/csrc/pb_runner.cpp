@@ -2,7 +2,7 @@
 //
 //   particlebot_run [config.cfg] [--set NAME VALUE]... [--engine fused|legacy] [--quiet]
 //                   [--frames DIR [--frame-size PIXELS]]
-//                   [--resume FILE] [--checkpoint FILE [--checkpoint-every SECONDS] [--checkpoint-steps N]]
+//                   [--resume FILE [--overwrite-csv]] [--checkpoint FILE [--checkpoint-every SECONDS] [--checkpoint-steps N]]
 //                   [--final-checkpoint FILE]
 //
 // --resume FILE continues a run (main.cpp:954-957 -> particlebot.cpp:369-411): FILE is either an exact checkpoint
@@ -10,6 +10,9 @@
 // random generators, and the length the CSV had: the resumed run is bit-identical to the uninterrupted one and the
 // CSV ends up byte-identical) or, as in the reference, a testing=1 CSV whose last complete row supplies time,
 // positions, velocities and radii (phases, dead set and force sums start afresh: the reference's lossy resume).
+// When that CSV is csv_filename itself -- the same file by device and inode, however the two paths are spelled -- the
+// run appends to it as the reference does (main.cpp:940-956); when it is another file, an existing non-empty
+// csv_filename is only truncated with --overwrite-csv.
 // --checkpoint FILE is rewritten (write to FILE.tmp, rename) every --checkpoint-every SECONDS of wall time
 // and/or every --checkpoint-steps timesteps, always at a point where the main loop is about to dump.
 //
@@ -26,6 +29,7 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -69,7 +73,7 @@ int main(int argc, char **argv) {
   std::string path = "example.cfg";
   std::vector<std::pair<std::string, std::string>> sets;
   Particlebot::Engine engine = Particlebot::Engine::Fused;
-  bool quiet = false;
+  bool quiet = false, overwriteCsv = false;
   std::string framesDir, resumePath, ckptPath, finalCkptPath;
   int frameSize = 800;
   double ckptEverySeconds = 0.0;
@@ -82,6 +86,8 @@ int main(int argc, char **argv) {
       engine = !strcmp(argv[++i], "legacy") ? Particlebot::Engine::Legacy : Particlebot::Engine::Fused;
     } else if (!strcmp(argv[i], "--quiet")) {
       quiet = true;
+    } else if (!strcmp(argv[i], "--overwrite-csv")) {
+      overwriteCsv = true;
     } else if (!strcmp(argv[i], "--frames") && i + 1 < argc) {
       framesDir = argv[++i];
     } else if (!strcmp(argv[i], "--frame-size") && i + 1 < argc) {
@@ -103,8 +109,8 @@ int main(int argc, char **argv) {
     } else {
       fprintf(stderr,
               "usage: %s [config.cfg] [--set NAME VALUE]... [--engine fused|legacy] [--quiet] "
-              "[--frames DIR [--frame-size PIXELS]] [--resume FILE] [--checkpoint FILE [--checkpoint-every SECONDS] "
-              "[--checkpoint-steps N]] [--final-checkpoint FILE]\n",
+              "[--frames DIR [--frame-size PIXELS]] [--resume FILE [--overwrite-csv]] [--checkpoint FILE "
+              "[--checkpoint-every SECONDS] [--checkpoint-steps N]] [--final-checkpoint FILE]\n",
               argv[0]);
       return 2;
     }
@@ -156,7 +162,22 @@ int main(int argc, char **argv) {
   }
   // the CSV: truncated on a fresh start (main.cpp:944); appended to when the run continues from its own last row
   // (main.cpp:940-956); cut back to the length the checkpoint recorded on an exact resume
-  const bool csvResumeInPlace = !resumePath.empty() && !exactResume && resumePath == cfg.csv_filename;
+  // "Its own": the SAME FILE, however it is spelled (./run.csv, an absolute path, a symlink) -- decided by device and
+  // inode, not by comparing strings; a resume from ANOTHER CSV never truncates an existing csv_filename silently
+  // (`--resume ./run.csv` with csv_filename run.csv destroyed every earlier row of the run).
+  bool csvResumeInPlace = false;
+  if (!resumePath.empty() && !exactResume) {
+    struct stat a, b;
+    const bool haveA = stat(resumePath.c_str(), &a) == 0, haveB = stat(cfg.csv_filename.c_str(), &b) == 0;
+    csvResumeInPlace = haveA && haveB && a.st_dev == b.st_dev && a.st_ino == b.st_ino;
+    if (!csvResumeInPlace && haveB && b.st_size > 0 && !overwriteCsv) {
+      fprintf(stderr,
+              "%s exists and is not the file being resumed (%s): refusing to truncate it; pass --overwrite-csv or "
+              "choose another csv_filename\n",
+              cfg.csv_filename.c_str(), resumePath.c_str());
+      return 1;
+    }
+  }
   FILE *fp = fopen(cfg.csv_filename.c_str(), exactResume ? "r+" : csvResumeInPlace ? "a" : "w+");
   if (!fp) {
     fprintf(stderr, "cannot open %s\n", cfg.csv_filename.c_str());

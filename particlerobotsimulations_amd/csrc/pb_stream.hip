@@ -20,6 +20,9 @@ namespace {
 // lane of the wave passes it (22 % of the trips on the bench lattice, 36 % in a random blob); ASUM = false (no
 // member reads absForce_a, pbSimSetForceSums) drops the Sum|F_attr| accumulation and its store; the once-per-bot
 // tail (friction, kick, actuation, integration) uses v_rcp/v_rsq forms instead of IEEE divisions and roots.
+#ifndef PB_STREAM_NEAR
+#define PB_STREAM_NEAR 1e-7f  // a candidate this close to contact (or closer, or in contact) goes to the contact pass
+#endif
 #ifndef PB_STREAM_CAP
 #define PB_STREAM_CAP 12  // contacts per lane listed in LDS (further ones are evaluated in place)
 #endif
@@ -127,15 +130,45 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
   float fr = 0.0f * absR[s];  // impl.cuh:688
   uint32_t cnt = 0;
 
+  // Round 4: the contact decision is the one discontinuity of the pair force (2.5 N of attraction floor against a
+  // spring that starts at 0), and a placed blob is full of pairs that touch EXACTLY (dist == reach to the last bit;
+  // held bots keep them so for hundreds of steps).  dist from v_rsq_f32 is 1-2 ulp off, which decided those pairs at
+  // random: 5-8 x the flips of an FMA-contracted build of the reference's own arithmetic
+  // (tests/test_gpu_fma_bracket.py).  So the first pass lists every candidate with gap < PB_STREAM_NEAR (~7 ulp of a
+  // typical distance) and THIS pass, a handful of trips per bot, decides: away from the threshold by the sign of
+  // the gap, within 2 * PB_STREAM_NEAR of it as the reference does -- IEEE root of the uncontracted dot product
+  // against the sum of the radii (impl.cuh:549-555).  A listed pair that is not in contact gets the attraction floor
+  // (gap < 0.0009: 2.5 N along n whatever the attraction constant, impl.cuh:581-583).
   auto contactOf = [&](uint32_t j, const float4 &q) __attribute__((always_inline)) {
     const float rx = q.x - me.x, ry = q.y - me.y;
-    const PbGeomS g = pbGeomS(rx, ry, fmaxf(__builtin_fmaf(rx, rx, ry * ry), 1e-30f));
-    const float2 vb = velIn[j];
-    float cx, cy;
-    const float mag = pbContactS(CK, g, me.z + q.z, vb.x - v.x, vb.y - v.y, cx, cy);
-    fx += cx;
-    fy += cy;
-    fr += mag;
+    const float d2 = fmaxf(__builtin_fmaf(rx, rx, ry * ry), 1e-30f);
+    PbGeomS g = pbGeomS(rx, ry, d2);
+    // The spring term is 1000 * (reach - dist): every ulp of dist (1.5e-8 at 0.2) is 1.5e-5 N, the largest rounding
+    // error of the whole force sum and what decides a resting bot's static-friction hold.  One Newton step on the
+    // v_rsq_f32 root (exact root of d2, pbDistUnitFast) for the handful of contacts of a bot: 3 instructions per
+    // contact trip, and the error of the contracted dot product is then the only one left, as in an FMA build.
+    {
+      const float h = 0.5f * __builtin_amdgcn_rsqf(d2), e = __builtin_fmaf(-g.dist, g.dist, d2);
+      g.dist = __builtin_fmaf(e, h, g.dist);
+    }
+    const float reach = me.z + q.z, gap = g.dist - reach;
+    bool contact = gap < 0.0f;
+    if (fabsf(gap) < 2.0f * PB_STREAM_NEAR) {
+      const float xx = rx * rx, d2e = xx + ry * ry;  // (-ffp-contract=off: two roundings, as the reference)
+      if (d2e > 0x1p-90f) contact = pbSqrtFast(d2e) < reach;  // == sqrtf on its domain (pbSelfTest: every float)
+    }
+    if (contact) {
+      const float2 vb = velIn[j];
+      float cx, cy;
+      const float mag = pbContactS(CK, g, reach, vb.x - v.x, vb.y - v.y, cx, cy);
+      fx += cx;
+      fy += cy;
+      fr += mag;
+    } else {
+      fx = __builtin_fmaf(fmin_attr, g.nx, fx);
+      fy = __builtin_fmaf(fmin_attr, g.ny, fy);
+      if (ASUM) fa += fmin_attr;
+    }
   };
   // No test for the bot's own slot in the common trip: with d2 clamped away from zero the self pair has n = 0 and
   // gap = -reach, so it lands in the contact block, which skips it.  (Two distinct bots at the same point, NaN in
@@ -149,19 +182,8 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
     float coef = pbFarCoefS(A, gap);
     // gap < near2: one of the two near bands or contact (gap < 0) -- rare: a wave-uniform branch on one ballot
     if (__builtin_amdgcn_ballot_w64(gap < near2) != 0ull) {
-      bool contact = gap < 0.0f;                                   // dist < reach
-      // Round 4: the contact decision is the one discontinuity of the pair force (2.5 N of attraction floor against
-      // a spring that starts at 0), and a placed blob is full of pairs that touch EXACTLY (dist == reach to the last
-      // bit; held bots keep them so for hundreds of steps).  dist from v_rsq_f32 is 1-2 ulp off, which decided those
-      // pairs at random: 5-8 x the flips of an FMA-contracted build of the reference's own arithmetic
-      // (tests/test_gpu_fma_bracket.py).  Within ~7 ulp of the threshold the decision is therefore taken as the
-      // reference takes it -- IEEE root of the uncontracted dot product against the sum of radii (impl.cuh:551-555);
-      // a wave-uniform branch inside the rare block, taken in well under 1 % of the trips.
-      if (__builtin_amdgcn_ballot_w64(fabsf(gap) < 1e-7f) != 0ull) {
-        const float rr = rx * rx, d2e = rr + ry * ry;
-        const bool exact = sqrtf(d2e) < me.z + q.z;
-        contact = fabsf(gap) < 1e-7f ? exact : contact;
-      }
+      // dist < reach -- or within a few ulp of it: the contact pass decides those exactly (contactOf)
+      const bool contact = gap < PB_STREAM_NEAR;
       const float K = PAYLOAD ? pbBandSlope(A) : slope0;
       const float band = gap < near1 ? fmin_attr : __builtin_fmaf(K, gap - near1, fmin_attr);
       coef = gap < near2 ? band : coef;

@@ -97,6 +97,32 @@ def test_resume_from_the_csv_like_the_reference(tmp_path):
     assert t1[0] == pytest.approx(t0[-1], abs=0.011) and t1[-1] >= 3.99 and t0[-1] <= 2.02
 
 
+def test_resume_recognises_its_own_csv_however_it_is_spelled(tmp_path):
+    """the same file named differently (./run.csv against run.csv, a symlink, an absolute path) is
+    still the run's own CSV -- appended to, never reopened with "w+" -- and a resume from ANOTHER CSV refuses to
+    truncate an existing csv_filename unless --overwrite-csv is given."""
+    base = [RUN, EX("example.cfg"), "--quiet", "--set", "csv_filename", "run.csv", "--set", "testing", "1", "--set",
+            "dump_interval", "0.5", "--set", "phase_std", "0"]
+    assert run(base + ["--set", "max_time", "2"], cwd=tmp_path).returncode == 0
+    before = open(tmp_path / "run.csv").read()
+    os.symlink(tmp_path / "run.csv", tmp_path / "link.csv")
+    for k, spelled in enumerate(["./run.csv", str(tmp_path / "run.csv"), "link.csv"]):
+        assert run(base + ["--set", "max_time", str(3 + k), "--resume", spelled], cwd=tmp_path).returncode == 0
+        now = open(tmp_path / "run.csv").read()
+        assert now.startswith(before) and len(now) > len(before), spelled
+        before = now
+    # another CSV as the source: run.csv exists and is not it -> refused, untouched
+    other = tmp_path / "other.csv"
+    other.write_text(before)
+    p = run(base + ["--set", "max_time", "7", "--resume", "other.csv"], cwd=tmp_path)
+    assert p.returncode == 1 and "refusing to truncate" in p.stderr and open(tmp_path / "run.csv").read() == before
+    p = run(base + ["--set", "max_time", "7", "--resume", "other.csv", "--overwrite-csv"], cwd=tmp_path)
+    assert p.returncode == 0 and not open(tmp_path / "run.csv").read().startswith(before[:len(before) // 2])
+    # ... and a csv_filename that does not exist yet is simply created
+    p = run(base[:5] + ["fresh.csv"] + base[6:] + ["--set", "max_time", "7", "--resume", "other.csv"], cwd=tmp_path)
+    assert p.returncode == 0 and os.path.getsize(tmp_path / "fresh.csv") > 0
+
+
 def test_pipelined_ensemble_stopped_and_resumed_equals_the_uninterrupted_run(tmp_path):
     """A 16-member ensemble in sub-batches of 8 with checkpoints at every summary row: stopped after 1500 of its
     3000 steps (sub-batch 0 in mid-run, sub-batch 1 not started... both stop at the step cap), resumed: the same rows
