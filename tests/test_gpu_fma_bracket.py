@@ -73,4 +73,4 @@ def test_streamlined_kernel_inside_the_bracket(pb, orc, case):
         assert w["max_abs"] <= fb.WINDOW * 2.5e-4, (case, r)
         assert r["break_p99"] is None or r["break_p99"] >= 20, (case, r)
     worst_bracket = max(bracket["flips_total"], rows["fma_powf"]["flips_total"])
-    assert hip["flips_total"] <= 10 * worst_bracket + 5, (case, hip, bracket)
+    assert hip["flips_total"] <= 3 * worst_bracket + 2, (case, hip, bracket)
