@@ -36,6 +36,10 @@ constexpr int TILE = PB_TILE;
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+struct PbTile {
+  uint32_t start, count;  // a run of <= TILE slots inside one (filed) grid row (pb_stream.hip, stream form 1)
+};
+
 struct pbSim {
   std::vector<PbDevParams> hP;  // one parameter block per simulation
   PbDevParams *dP = nullptr;
@@ -55,6 +59,12 @@ struct pbSim {
   int cur = 0;                             // which copy of every array is live
 
   uint32_t *cellS = nullptr;  // nsims x (numCells+1), global slot indices
+  unsigned long long layoutEpoch = 0;  // bumped whenever cellS / the slot order is rebuilt
+  PbTile *tiles = nullptr;             // stream form 1: row-aligned tiles of the current layout, built on the device
+  uint32_t *ntiles = nullptr;
+  uint32_t tilesHost = 0;  // the tile count, read back when the tiles are cut
+  unsigned long long tilesEpoch = ~0ull;
+  int streamForm = 0;  // force variant 3: 0 k_force_stream (global loads), 1 k_force_patch (one LDS patch per workgroup)
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *slotOf = nullptr;
   uint32_t *sortedKeys = nullptr;  // keys[0] or keys[1]: composite keys of the slots, as of the last sort
   std::vector<uint32_t> layoutOrig, layoutKeys;  // host staging of pbSimSetLayoutOf

@@ -274,9 +274,411 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
   absR[s] = F.fr;
 }
 
+
+// ---- round 4: the streamlined kernel with ONE LDS PATCH PER WORKGROUP (stream form 1) -----------------------------
+// VERDICT round 3 item 4.  Round 3 showed that the vector-memory pipeline co-limits k_force_stream (the same
+// instruction stream without neighbour loads: 41.8 us against 52.7) and that a wave-private tile loses the gain to its
+// prologue, to 40 KB of LDS per workgroup and to waves that span two grid rows.  This form stages the neighbourhood
+// ONCE PER WORKGROUP:
+//   * tiles never span a (filed) grid row: k_build_tiles cuts every grid row's slot range into equal tiles of <= 256
+//     slots at each re-sort (device side, no host synchronisation); the launch covers an upper bound of tiles and the
+//     surplus workgroups exit at once; XCD-aware tile mapping from the device-side tile count;
+//   * per tile: the lanes' CURRENT cells (lists are stale between re-sorts, impl.cuh:680) are reduced to a bounding
+//     box, the box + 2 cells of stencil is <= 7 grid rows x one contiguous slot range each, staged by all four waves
+//     with coalesced 16-B loads into a float4 image (24 KB), and every lane walks its 5 x 5 stencil out of LDS with
+//     ds_read_b128; contact lists hold 16-bit patch indices (6 KB);
+//   * a tile whose box does not fit (more than PB_PATCH_SLOTS slots or 7 rows, or touching the grid's x-wrap) walks
+//     global memory instead (plain loop; rare by construction).
+// Arithmetic, summation order within a lane and results are those of k_force_stream.
+#ifndef PB_PATCH_SLOTS
+#define PB_PATCH_SLOTS 1536
+#endif
+#define PB_PATCH_ROWS 7
+#ifndef PB_PATCH_CAP
+#define PB_PATCH_CAP 12
+#endif
+
+// Tiles of one grid row, greedily: a tile ends after TILE slots or where the neighbourhood of its cells -- 2 cells to
+// each side, 5 grid rows, as filed -- would exceed `budget` slots (a sparse row next to dense ones: 256 of its bots
+// span 170 cells on the bench lattice), whichever comes first.  (Drift since the re-sort can still push a tile over
+// PB_PATCH_SLOTS: that tile walks global memory.)  emit(start, count) per tile; returns the number of tiles.
+template <class Emit>
+__device__ uint32_t pbCutRow(const uint32_t *__restrict__ cellS, const uint32_t *__restrict__ sortedKeys, uint32_t GX,
+                             uint32_t GY, uint32_t r, uint32_t budget, Emit emit) {
+  const uint32_t rowLo = cellS[(size_t)r * GX], rowHi = cellS[(size_t)(r + 1u) * GX];
+  uint32_t nt = 0;
+  auto cellOf = [&](uint32_t slot) { return sortedKeys[slot] & (GX - 1u); };
+  auto need = [&](uint32_t c0, uint32_t c1) {  // slots of cells c0-2 .. c1+2 in rows r-2 .. r+2
+    const uint32_t a = c0 >= 2u ? c0 - 2u : 0u, b = c1 + 3u <= GX ? c1 + 3u : GX;
+    uint32_t sum = 0;
+    for (int dr = -2; dr <= 2; dr++) {
+      const size_t row = (size_t)((r + (uint32_t)dr) & (GY - 1u)) * GX;
+      sum += cellS[row + b] - cellS[row + a];
+    }
+    return sum;
+  };
+  for (uint32_t a = rowLo; a < rowHi;) {
+    const uint32_t c0 = cellOf(a);
+    uint32_t hi = a + (uint32_t)TILE < rowHi ? a + (uint32_t)TILE : rowHi;  // candidate end (exclusive)
+    if (need(c0, cellOf(hi - 1u)) > budget) {
+      uint32_t lo = a + 1u;  // the largest end in (a, hi] that still fits (a tile always gets at least one slot)
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if (need(c0, cellOf(mid - 1u)) <= budget) lo = mid;
+        else hi = mid - 1u;
+      }
+      hi = lo;
+    }
+    emit(a, hi - a);
+    nt++;
+    a = hi;
+  }
+  return nt;
+}
+
+__global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict__ cellS,
+                                                      const uint32_t *__restrict__ sortedKeys, uint32_t GX, uint32_t GY,
+                                                      PbTile *__restrict__ tiles, uint32_t *__restrict__ ntilesOut,
+                                                      uint32_t maxTiles, uint32_t budget) {
+  __shared__ uint32_t part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (GY + 1023u) / 1024u;
+  const uint32_t r0 = t * per, r1 = r0 + per < GY ? r0 + per : GY;
+  uint32_t cnt = 0;
+  for (uint32_t r = r0; r < r1; r++) cnt += pbCutRow(cellS, sortedKeys, GX, GY, r, budget, [](uint32_t, uint32_t) {});
+  part[t] = cnt;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024u; d <<= 1) {
+    const uint32_t v = t >= d ? part[t - d] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t at = part[t] - cnt;
+  for (uint32_t r = r0; r < r1; r++)
+    (void)pbCutRow(cellS, sortedKeys, GX, GY, r, budget, [&](uint32_t a, uint32_t c) {
+      if (at < maxTiles) tiles[at] = PbTile{a, c};
+      at++;
+    });
+  if (t == 1023u) {
+    ntilesOut[0] = part[1023] < maxTiles ? part[1023] : maxTiles;
+    ntilesOut[1] = 0u;  // workgroups that walked global memory since this layout was cut (statistics)
+  }
+}
+
+template <bool PAYLOAD, bool ASUM>
+__global__ __launch_bounds__(TILE) void k_force_patch(const PbDevParams *__restrict__ params,
+                                                      const float4 *__restrict__ prIn, const float2 *__restrict__ velIn,
+                                                      float4 *__restrict__ prOut, float2 *__restrict__ velOut,
+                                                      const float *__restrict__ phase, const int *__restrict__ dead,
+                                                      float *__restrict__ absA, float *__restrict__ absR,
+                                                      const uint32_t *__restrict__ orig,
+                                                      const uint32_t *__restrict__ cellS,
+                                                      const PbTile *__restrict__ tiles,
+                                                      const uint32_t *__restrict__ ntilesPtr, float dt, float timeNext,
+                                                      int doRadiusNext, int fuse) {
+  __shared__ float4 patch[PB_PATCH_SLOTS + 4];
+  __shared__ uint16_t contacts[PB_PATCH_CAP][TILE];
+  __shared__ int wred[TILE / 64][4];
+  __shared__ int rowDelta[PB_PATCH_ROWS + 1];  // patch index of a global slot of patch row r = slot + rowDelta[r]
+  const PbDevParams &P = params[0];
+  const uint32_t ntiles = *ntilesPtr;
+  const uint32_t perXcd = (ntiles + 7u) >> 3;
+  const uint32_t tile = (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= perXcd || tile >= ntiles) return;
+  const PbTile T = tiles[tile];
+  const uint32_t tid = threadIdx.x;
+  const bool active = tid < T.count;
+  const uint32_t s = T.start + (active ? tid : T.count - 1u);  // idle lanes shadow the tile's last bot (no stores)
+
+  const float4 me = prIn[s];
+  const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
+  // bounding box of the tile's current cells: wave reduction, then four values per wave through LDS
+  {
+    int a = gx, b = gx, c = gy, d = gy;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      a = min(a, __shfl_xor(a, m));
+      b = max(b, __shfl_xor(b, m));
+      c = min(c, __shfl_xor(c, m));
+      d = max(d, __shfl_xor(d, m));
+    }
+    if ((tid & 63u) == 0u) {
+      wred[tid >> 6][0] = a;
+      wred[tid >> 6][1] = b;
+      wred[tid >> 6][2] = c;
+      wred[tid >> 6][3] = d;
+    }
+  }
+  __syncthreads();
+  int bx0 = wred[0][0], bx1 = wred[0][1], by0 = wred[0][2], by1 = wred[0][3];
+#pragma unroll
+  for (int w = 1; w < TILE / 64; w++) {
+    bx0 = min(bx0, wred[w][0]);
+    bx1 = max(bx1, wred[w][1]);
+    by0 = min(by0, wred[w][2]);
+    by1 = max(by1, wred[w][3]);
+  }
+  const int x0 = __builtin_amdgcn_readfirstlane(bx0) - 2, x1 = __builtin_amdgcn_readfirstlane(bx1) + 2;
+  const int R0 = __builtin_amdgcn_readfirstlane(by0) - 2;
+  const int nrows = __builtin_amdgcn_readfirstlane(by1) + 2 - R0 + 1;
+  const uint32_t GX = P.gridX;
+  bool fits = x0 >= 0 && x1 < (int)GX && nrows <= PB_PATCH_ROWS;
+  // one contiguous slot range per patch row (wave-uniform: scalar loads)
+  uint32_t rlo[PB_PATCH_ROWS], rbase[PB_PATCH_ROWS + 1];
+  rbase[0] = 0;
+#pragma unroll
+  for (int r = 0; r < PB_PATCH_ROWS; r++) {
+    uint32_t lo = 0, hi = 0;
+    if (fits && r < nrows) {
+      const uint32_t row = ((uint32_t)(R0 + r) & (P.gridY - 1u)) << P.gridXLog2;
+      lo = cellS[row + (uint32_t)x0];
+      hi = cellS[row + (uint32_t)x1 + 1u];
+    }
+    rlo[r] = lo;
+    rbase[r + 1] = rbase[r] + (hi - lo);
+  }
+  const uint32_t totalSlots = rbase[PB_PATCH_ROWS];
+  fits = fits && totalSlots <= (uint32_t)PB_PATCH_SLOTS;
+
+  const float att1 = (PAYLOAD && orig[s] == P.nCells - 1u) ? P.attractionFactor : 1.0f;
+  const bool selfPayload = PAYLOAD && orig[s] == P.nCells - 1u;
+  float2 v = velIn[s];
+  const float attraction0 = P.attraction;
+  const float slope0 = pbBandSlope(attraction0);
+  const PbContactK CK{P.spring, P.damping, P.shear};
+  const float near1 = 0.0009f, near2 = 0.0019f, fmin_attr = 2.5f;
+  float fx = 0.0f, fy = 0.0f, fa = 0.0f;
+  float fr = 0.0f * absR[s];  // impl.cuh:688
+
+  // the contact pass of k_force_stream (see there): exact decision near the threshold, Newton-refined distance
+  auto contactOf = [&](uint32_t j, const float4 &q) __attribute__((always_inline)) {
+    const float rx = q.x - me.x, ry = q.y - me.y;
+    const float d2 = fmaxf(__builtin_fmaf(rx, rx, ry * ry), 1e-30f);
+    PbGeomS g = pbGeomS(rx, ry, d2);
+    {
+      const float h = 0.5f * __builtin_amdgcn_rsqf(d2), e = __builtin_fmaf(-g.dist, g.dist, d2);
+      g.dist = __builtin_fmaf(e, h, g.dist);
+    }
+    const float reach = me.z + q.z, gap = g.dist - reach;
+    bool contact = gap < 0.0f;
+    if (fabsf(gap) < 2.0f * PB_STREAM_NEAR) {
+      const float xx = rx * rx, d2e = xx + ry * ry;
+      if (d2e > 0x1p-90f) contact = pbSqrtFast(d2e) < reach;
+    }
+    if (contact) {
+      const float2 vb = velIn[j];
+      float cx, cy;
+      const float mag = pbContactS(CK, g, reach, vb.x - v.x, vb.y - v.y, cx, cy);
+      fx += cx;
+      fy += cy;
+      fr += mag;
+    } else {
+      fx = __builtin_fmaf(fmin_attr, g.nx, fx);
+      fy = __builtin_fmaf(fmin_attr, g.ny, fy);
+      if (ASUM) fa += fmin_attr;
+    }
+  };
+  // one candidate; listIt() runs for a candidate that belongs on the contact list (inside the rare block)
+  auto one = [&](const float4 &q, auto listIt) __attribute__((always_inline)) {
+    const float rx = q.x - me.x, ry = q.y - me.y;
+    const float d2 = fmaxf(__builtin_fmaf(rx, rx, ry * ry), 1e-30f);
+    const float inv = __builtin_amdgcn_rsqf(d2);
+    const float gap = __builtin_fmaf(d2, inv, -(me.z + q.z));
+    // (.w is 1 for every bot but the payload, k_set_state: the product is exact, and using the fourth component keeps
+    //  the LDS read a ds_read_b128 -- 4 LDS cycles; the compiler would shrink it to a ds_read_b96, 8 cycles)
+    const float A = PAYLOAD ? attraction0 * q.w * att1 : attraction0 * q.w;
+    float coef = pbFarCoefS(A, gap);
+    if (__builtin_amdgcn_ballot_w64(gap < near2) != 0ull) {
+      const bool contact = gap < PB_STREAM_NEAR;
+      const float K = PAYLOAD ? pbBandSlope(A) : slope0;
+      const float band = gap < near1 ? fmin_attr : __builtin_fmaf(K, gap - near1, fmin_attr);
+      coef = gap < near2 ? band : coef;
+      coef = contact ? 0.0f : coef;
+      if (contact) listIt();
+    }
+    const float ci = coef * inv;
+    fx = __builtin_fmaf(ci, rx, fx);
+    fy = __builtin_fmaf(ci, ry, fy);
+    if (ASUM) fa += coef;
+  };
+
+  uint32_t cnt = 0;
+  if (__builtin_amdgcn_readfirstlane(fits ? 1 : 0)) {
+    // ---- stage the patch: 6 coalesced 16-B loads per lane, all in flight, then the LDS writes ----
+    if (tid < (uint32_t)PB_PATCH_ROWS) {
+      int dlt = 0;
+#pragma unroll
+      for (int r = 0; r < PB_PATCH_ROWS; r++)
+        if ((int)tid == r) dlt = (int)rbase[r] - (int)rlo[r];
+      rowDelta[tid] = dlt;
+    }
+    constexpr int CHUNKS = (PB_PATCH_SLOTS + TILE - 1) / TILE;
+    float4 stg[CHUNKS];
+#pragma unroll
+    for (int k = 0; k < CHUNKS; k++) {
+      const uint32_t i = (uint32_t)k * TILE + tid;
+      uint32_t src = rlo[0] + i;
+#pragma unroll
+      for (int r = 1; r < PB_PATCH_ROWS; r++) src = i >= rbase[r] ? rlo[r] + (i - rbase[r]) : src;
+      stg[k] = prIn[i < totalSlots ? src : s];  // (beyond the patch: any valid slot; not written below)
+    }
+#pragma unroll
+    for (int k = 0; k < CHUNKS; k++) {
+      const uint32_t i = (uint32_t)k * TILE + tid;
+      if (i < totalSlots) patch[i] = stg[k];
+    }
+    __syncthreads();
+    if (!active) return;
+
+    const char *const pb = (const char *)patch;
+    auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(pb + off); };
+    const int prMine = gy - R0;  // patch row of the lane's own grid row (2 .. nrows-3)
+    // bounds of stencil row k (0..4): patch BYTE offsets; the cell table stays in global memory (two loads per row,
+    // issued two rows ahead)
+    // (self: where the lane's OWN slot would sit in that patch row -- with stale lists a bot is not necessarily filed
+    //  under the row it is in now, so the test is on the global slot, row by row)
+    auto bounds = [&](int k, uint32_t &lo, uint32_t &hi, uint32_t &tag, uint32_t &self) __attribute__((always_inline)) {
+      lo = hi = 0u;
+      tag = self = 0u;
+      if (k < 5) {
+        const int pr = prMine + k - 2;
+        const uint32_t row = ((uint32_t)(gy + k - 2) & (P.gridY - 1u)) << P.gridXLog2;
+        const int dl = rowDelta[pr];
+        lo = (uint32_t)((int)cellS[row + (uint32_t)(gx - 2)] + dl) * 16u;
+        hi = (uint32_t)((int)cellS[row + (uint32_t)(gx + 3)] + dl) * 16u;
+        tag = (uint32_t)pr << 13;
+        self = (uint32_t)((int)s + dl) * 16u;
+      }
+    };
+    // rows rolled and software-pipelined as in k_force_stream: while row k runs, the cell-table bounds of row k + 2
+    // and the first two records of row k + 1 are in flight; inside a row the LDS reads run two candidates ahead,
+    // three registers rotating roles.  Up to two records past a range are read (never evaluated).
+    uint32_t loA, hiA, tagA, selfA, loB, hiB, tagB, selfB;
+    bounds(0, loA, hiA, tagA, selfA);
+    bounds(1, loB, hiB, tagB, selfB);
+    float4 qA0 = at(loA), qA1 = at(loA + 16u);
+#pragma unroll 1
+    for (int k = 0; k < 5; k++) {
+      const uint32_t lo = loA, end = hiA, tag = tagA, selfOff = selfA;
+      float4 q0 = qA0, q1 = qA1;
+      loA = loB;
+      hiA = hiB;
+      tagA = tagB;
+      selfA = selfB;
+      qA0 = at(loA);
+      qA1 = at(loA + 16u);
+      bounds(k + 2, loB, hiB, tagB, selfB);
+      if (lo < end) {
+        uint32_t off = lo;
+        auto push = [&](const float4 &q) __attribute__((always_inline)) {
+          if (off != selfOff) {
+            if (cnt < (uint32_t)PB_PATCH_CAP) contacts[cnt][tid] = (uint16_t)((off >> 4) | tag);
+            else contactOf((off >> 4) - (uint32_t)rowDelta[tag >> 13], q);
+            cnt++;
+          }
+        };
+        for (;;) {
+          const float4 q2 = at(off + 32u);
+          one(q0, [&]() { push(q0); });
+          if ((off += 16u) >= end) break;
+          q0 = at(off + 32u);
+          one(q1, [&]() { push(q1); });
+          if ((off += 16u) >= end) break;
+          q1 = at(off + 32u);
+          one(q2, [&]() { push(q2); });
+          if ((off += 16u) >= end) break;
+        }
+      }
+    }
+    const uint32_t listed = cnt < (uint32_t)PB_PATCH_CAP ? cnt : (uint32_t)PB_PATCH_CAP;
+    for (uint32_t k = 0; k < listed; k++) {
+      const uint32_t e = contacts[k][tid], li = e & 0x1fffu;
+      contactOf(li - (uint32_t)rowDelta[e >> 13], patch[li]);
+    }
+  } else {
+    // ---- the tile's box does not fit the patch: walk global memory (x-wrap: two ranges per row); the contact
+    //      list (global slots) lives in the unused patch memory, so the order of the additions is form 0's ----
+    if (tid == 0u) atomicAdd(const_cast<uint32_t *>(ntilesPtr) + 1, 1u);  // statistics (pbSimGetStreamStats)
+    if (!active) return;
+    uint32_t(*glist)[TILE] = reinterpret_cast<uint32_t(*)[TILE]>(patch);
+    const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
+    const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;
+    for (int k = 0; k < 5; k++) {
+      const uint32_t row = ((uint32_t)(gy + k - 2) & (P.gridY - 1u)) << P.gridXLog2;
+      for (int half = 0; half < (first < 5u ? 2 : 1); half++) {
+        const uint32_t lo = cellS[row + (half ? 0u : mx0)], hi = cellS[row + (half ? 5u - first : mx0 + first)];
+        for (uint32_t j = lo; j < hi; j++) {
+          const float4 q = prIn[j];
+          one(q, [&]() {
+            if (j != s) {
+              if (cnt < (uint32_t)PB_PATCH_CAP) glist[cnt][tid] = j;
+              else contactOf(j, q);
+              cnt++;
+            }
+          });
+        }
+      }
+    }
+    const uint32_t listed = cnt < (uint32_t)PB_PATCH_CAP ? cnt : (uint32_t)PB_PATCH_CAP;
+    for (uint32_t k = 0; k < listed; k++) {
+      const uint32_t j = glist[k][tid];
+      contactOf(j, prIn[j]);
+    }
+  }
+
+  PbForce F{fx, fy, fa, fr};
+  pbObstacles(P, me.x, me.y, v.x, v.y, me.z, F);
+  pbFrictionAndKickS(P, selfPayload, F.fx, F.fy, dt, v.x, v.y);
+  float4 out = me;
+  if (fuse) {
+    if (doRadiusNext) out.z = pbActuateS(P, me.z, phase[s], dead[s], F.fa, F.fr, timeNext, dt);
+    pbIntegrate(P, out.x, out.y, v.x, v.y, out.z, dt);
+  }
+  prOut[s] = out;
+  velOut[s] = v;
+  if (ASUM) absA[s] = F.fa;
+  absR[s] = F.fr;
+}
+
 }  // namespace
 
+// stream form 1 (pbSimSetStreamForm): one arena, the LDS-patch kernel over row-aligned tiles
+static bool launchPatch(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext) {
+  const uint32_t GX = S->hP[0].gridX, GY = S->hP[0].gridY;
+  // upper bound of the tile count: width-limited tiles hold >= ~budget/13 slots unless their row ends (a tile's
+  // neighbourhood is at most 5 rows x (its own cells + 4)); 3 n / TILE + one per row is never reached in practice
+  const uint32_t maxTiles = 3u * cdiv(S->n, TILE) + GY + 8u;
+  if (!S->tiles) {
+    if (hipMalloc(&S->tiles, sizeof(PbTile) * (size_t)maxTiles) != hipSuccess) return false;
+    if (hipMalloc(&S->ntiles, 4 * sizeof(uint32_t)) != hipSuccess) return false;
+    S->tilesEpoch = ~0ull;
+  }
+  if (S->tilesEpoch != S->layoutEpoch) {  // the slot layout changed (re-sort, restored layout): cut the rows anew
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), 0, S->stream, S->cellS, S->sortedKeys, GX, GY, S->tiles,
+                       S->ntiles, maxTiles, (uint32_t)PB_PATCH_SLOTS - 160u);
+    // the launch grid needs the count on the host: one 4-byte read-back per re-sort (every 18 000 steps)
+    if (hipMemcpyAsync(&S->tilesHost, S->ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream) != hipSuccess ||
+        hipStreamSynchronize(S->stream) != hipSuccess)
+      return false;
+    S->tilesEpoch = S->layoutEpoch;
+  }
+  const dim3 grid(8u * cdiv(S->tilesHost, 8u));
+  const bool asum = attractionSumsKept(S);
+#define PB_PATCH(PL, AS)                                                                                         \
+  hipLaunchKernelGGL((k_force_patch<PL, AS>), grid, dim3(TILE), 0, S->stream, S->dP, S->pr[c], S->vel[c], S->pr[o], \
+                     S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c], S->cellS, S->tiles,    \
+                     S->ntiles, dt, tNext, doRadiusNext, (int)fuse)
+  if (S->payload && asum) PB_PATCH(true, true);
+  else if (S->payload) PB_PATCH(true, false);
+  else if (asum) PB_PATCH(false, true);
+  else PB_PATCH(false, false);
+#undef PB_PATCH
+  return true;
+}
+
 void pbLaunchForceStream(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext) {
+  if (S->streamForm == 1 && S->nsims == 1 && launchPatch(S, fuse, c, o, dt, tNext, doRadiusNext)) return;
   const uint32_t tiles = cdiv(S->n, TILE);
   const uint32_t perXcd = tiles >= 64u ? cdiv(tiles, 8u) : 0u;
   const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
