@@ -36,8 +36,12 @@ constexpr int TILE = PB_TILE;
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+#ifndef PB_BAND
+#define PB_BAND 4  // grid rows per tile band of stream form 1 (pb_stream.hip)
+#endif
 struct PbTile {
-  uint32_t start, count;  // a run of <= TILE slots inside one (filed) grid row (pb_stream.hip, stream form 1)
+  // <= TILE bots filed under a block of cells: one slot run per band row; cum[j] = bots in rows 0..j
+  uint32_t start[PB_BAND], cum[PB_BAND];
 };
 
 struct pbSim {

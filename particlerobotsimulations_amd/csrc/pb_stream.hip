@@ -280,72 +280,138 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
 // instruction stream without neighbour loads: 41.8 us against 52.7) and that a wave-private tile loses the gain to its
 // prologue, to 40 KB of LDS per workgroup and to waves that span two grid rows.  This form stages the neighbourhood
 // ONCE PER WORKGROUP:
-//   * tiles never span a (filed) grid row: k_build_tiles cuts every grid row's slot range into equal tiles of <= 256
-//     slots at each re-sort (device side, no host synchronisation); the launch covers an upper bound of tiles and the
-//     surplus workgroups exit at once; XCD-aware tile mapping from the device-side tile count;
+//   * a tile is the <= 256 bots filed under a BLOCK of cells, PB_BAND grid rows high (pbCutBand, k_build_tiles: cut at
+//     each re-sort on the device; one 4-byte read-back gives the launch its grid); XCD-aware tile order;
 //   * per tile: the lanes' CURRENT cells (lists are stale between re-sorts, impl.cuh:680) are reduced to a bounding
-//     box, the box + 2 cells of stencil is <= 7 grid rows x one contiguous slot range each, staged by all four waves
-//     with coalesced 16-B loads into a float4 image (24 KB), and every lane walks its 5 x 5 stencil out of LDS with
-//     ds_read_b128; contact lists hold 16-bit patch indices (6 KB);
-//   * a tile whose box does not fit (more than PB_PATCH_SLOTS slots or 7 rows, or touching the grid's x-wrap) walks
-//     global memory instead (plain loop; rare by construction).
+//     box, the box + 2 cells of stencil is <= PB_BAND + 6 grid rows x one contiguous slot range each, staged by all
+//     four waves with coalesced 16-B loads into a float4 image (16 KB), and every lane walks its 5 x 5 stencil out of
+//     LDS with ds_read_b128; contact lists hold 16-bit patch indices (5 KB);
+//   * a tile whose box does not fit (more than PB_PATCH_SLOTS slots or PB_BAND + 6 rows, or touching the grid's
+//     x-wrap) walks global memory instead (plain loop; rare by construction).
+// (First built over strips of ONE grid row: 64.7 us per step at 10^6 bots against form 0's 53.0 -- sparse rows limit a
+//  strip to ~200 bots, 30 KB of LDS leave 5 workgroups per CU, and a row's bots spread over three rows once they move.)
 // Arithmetic, summation order within a lane and results are those of k_force_stream.
 #ifndef PB_PATCH_SLOTS
-#define PB_PATCH_SLOTS 1536
+#define PB_PATCH_SLOTS 1024  // 16 KB of float4 records
 #endif
-#define PB_PATCH_ROWS 7
-#ifndef PB_PATCH_CAP
-#define PB_PATCH_CAP 12
-#endif
+#define PB_PATCH_ROWS (PB_BAND + 6)  // the band, two stencil rows on each side, one row of drift on each side
+// the same list length as form 0: a bot with more contacts evaluates the surplus in place, i.e. in another order
+#define PB_PATCH_CAP PB_STREAM_CAP
+// a contact-list entry: patch index (< 2^11) | patch row << 11, in 16 bits
+#define PB_PATCH_TAG_SHIFT 11
+static_assert(PB_PATCH_SLOTS + 4 <= (1 << PB_PATCH_TAG_SHIFT) && PB_PATCH_ROWS <= 16, "contact-list entries are 16 bits");
+// what a tile's neighbourhood may need AS FILED (band + 4 rows) so that one more row of drift on each side still fits
+#define PB_PATCH_BUDGET ((PB_PATCH_SLOTS * (PB_BAND + 4)) / (PB_BAND + 6) - 32)
 
-// Tiles of one grid row, greedily: a tile ends after TILE slots or where the neighbourhood of its cells -- 2 cells to
-// each side, 5 grid rows, as filed -- would exceed `budget` slots (a sparse row next to dense ones: 256 of its bots
-// span 170 cells on the bench lattice), whichever comes first.  (Drift since the re-sort can still push a tile over
-// PB_PATCH_SLOTS: that tile walks global memory.)  emit(start, count) per tile; returns the number of tiles.
+// Tiles of one BAND of PB_BAND grid rows, greedily along x: a tile is the bots filed under the cells of columns
+// c0..c1 of the band's rows -- PB_BAND slot ranges -- and ends where one more column would exceed TILE bots or push
+// its neighbourhood as filed (columns c0-2..c1+2 of rows band-2..band+PB_BAND+1) over `budget` slots.  A column that
+// alone exceeds either (pathological compression) is cut row by row into runs of <= TILE slots.  Two-dimensional
+// tiles instead of strips of one row: the staged neighbourhood is (PB_BAND+4)/PB_BAND of... 3x the tile's own bots
+// instead of 5x, it fits 16 KB with room for the rows that stale lists add (a while after a re-sort the bots filed
+// under one row sit in three), and tiles fill their 256 lanes whatever the row densities are.
+// emit(tile) per tile; returns the number of tiles.
 template <class Emit>
-__device__ uint32_t pbCutRow(const uint32_t *__restrict__ cellS, const uint32_t *__restrict__ sortedKeys, uint32_t GX,
-                             uint32_t GY, uint32_t r, uint32_t budget, Emit emit) {
-  const uint32_t rowLo = cellS[(size_t)r * GX], rowHi = cellS[(size_t)(r + 1u) * GX];
-  uint32_t nt = 0;
-  auto cellOf = [&](uint32_t slot) { return sortedKeys[slot] & (GX - 1u); };
-  auto need = [&](uint32_t c0, uint32_t c1) {  // slots of cells c0-2 .. c1+2 in rows r-2 .. r+2
+__device__ uint32_t pbCutBand(const uint32_t *__restrict__ cellS, uint32_t GX, uint32_t GY, uint32_t band, uint32_t budget,
+                              Emit emit) {
+  const uint32_t R = band * (uint32_t)PB_BAND;
+  size_t row[PB_BAND];
+  for (int j = 0; j < PB_BAND; j++) row[j] = (size_t)(R + (uint32_t)j) * GX;
+  // nothing filed under the band at all?
+  uint32_t any = 0;
+  for (int j = 0; j < PB_BAND; j++)
+    if (R + (uint32_t)j < GY) any += cellS[row[j] + GX] - cellS[row[j]];
+  if (!any) return 0;
+  auto need = [&](uint32_t c0, uint32_t c1) {
     const uint32_t a = c0 >= 2u ? c0 - 2u : 0u, b = c1 + 3u <= GX ? c1 + 3u : GX;
     uint32_t sum = 0;
-    for (int dr = -2; dr <= 2; dr++) {
-      const size_t row = (size_t)((r + (uint32_t)dr) & (GY - 1u)) * GX;
-      sum += cellS[row + b] - cellS[row + a];
+    for (int dr = -2; dr < PB_BAND + 2; dr++) {
+      const size_t rr = (size_t)((R + (uint32_t)dr) & (GY - 1u)) * GX;
+      sum += cellS[rr + b] - cellS[rr + a];
     }
     return sum;
   };
-  for (uint32_t a = rowLo; a < rowHi;) {
-    const uint32_t c0 = cellOf(a);
-    uint32_t hi = a + (uint32_t)TILE < rowHi ? a + (uint32_t)TILE : rowHi;  // candidate end (exclusive)
-    if (need(c0, cellOf(hi - 1u)) > budget) {
-      uint32_t lo = a + 1u;  // the largest end in (a, hi] that still fits (a tile always gets at least one slot)
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1u) >> 1;
-        if (need(c0, cellOf(mid - 1u)) <= budget) lo = mid;
-        else hi = mid - 1u;
-      }
-      hi = lo;
+  // The tile's rows are listed by falling bot count: lanes are dealt to waves in that order, so a wave mostly holds
+  // bots of rows of like density, whose stencil rows have like lengths (the sweep runs stencil row by stencil row: a
+  // wave that mixes a dense and a sparse row of the bench lattice makes 75 trips instead of 60).
+  auto emitCols = [&](uint32_t c0, uint32_t c1) {
+    uint32_t st[PB_BAND], ct[PB_BAND];
+    for (int j = 0; j < PB_BAND; j++) {
+      const bool in = R + (uint32_t)j < GY;
+      st[j] = in ? cellS[row[j] + c0] : 0u;
+      ct[j] = in ? cellS[row[j] + c1 + 1u] - st[j] : 0u;
     }
-    emit(a, hi - a);
+    for (int a = 1; a < PB_BAND; a++)  // insertion sort, stable
+      for (int b = a; b > 0 && ct[b] > ct[b - 1]; b--) {
+        const uint32_t ts = st[b], tc = ct[b];
+        st[b] = st[b - 1];
+        ct[b] = ct[b - 1];
+        st[b - 1] = ts;
+        ct[b - 1] = tc;
+      }
+    PbTile t;
+    uint32_t acc = 0;
+    for (int j = 0; j < PB_BAND; j++) {
+      t.start[j] = st[j];
+      acc += ct[j];
+      t.cum[j] = acc;
+    }
+    emit(t);
+  };
+  uint32_t nt = 0, c0 = 0, count = 0;
+  bool open = false;
+  for (uint32_t x = 0; x < GX; x++) {
+    uint32_t col = 0;
+    for (int j = 0; j < PB_BAND; j++)
+      if (R + (uint32_t)j < GY) col += cellS[row[j] + x + 1u] - cellS[row[j] + x];
+    if (!col) continue;
+    if (open && (count + col > (uint32_t)TILE || need(c0, x) > budget)) {
+      emitCols(c0, x - 1u);  // (empty columns at the tile's end cost nothing)
+      nt++;
+      open = false;
+    }
+    if (!open) {
+      if (col > (uint32_t)TILE || need(x, x) > budget) {
+        // one column too many for a tile: its rows one at a time, in runs of <= TILE slots
+        for (int j = 0; j < PB_BAND; j++) {
+          if (R + (uint32_t)j >= GY) continue;
+          const uint32_t lo = cellS[row[j] + x], hi = cellS[row[j] + x + 1u];
+          for (uint32_t a = lo; a < hi; a += (uint32_t)TILE) {
+            PbTile t;
+            const uint32_t c = hi - a < (uint32_t)TILE ? hi - a : (uint32_t)TILE;
+            for (int i = 0; i < PB_BAND; i++) {
+              t.start[i] = a;
+              t.cum[i] = i < j ? 0u : c;
+            }
+            emit(t);
+            nt++;
+          }
+        }
+        continue;
+      }
+      open = true;
+      c0 = x;
+      count = 0;
+    }
+    count += col;
+  }
+  if (open) {
+    emitCols(c0, GX - 1u);
     nt++;
-    a = hi;
   }
   return nt;
 }
 
-__global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict__ cellS,
-                                                      const uint32_t *__restrict__ sortedKeys, uint32_t GX, uint32_t GY,
+__global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict__ cellS, uint32_t GX, uint32_t GY,
                                                       PbTile *__restrict__ tiles, uint32_t *__restrict__ ntilesOut,
                                                       uint32_t maxTiles, uint32_t budget) {
   __shared__ uint32_t part[1024];
   const uint32_t t = threadIdx.x;
-  const uint32_t per = (GY + 1023u) / 1024u;
-  const uint32_t r0 = t * per, r1 = r0 + per < GY ? r0 + per : GY;
+  const uint32_t bands = (GY + (uint32_t)PB_BAND - 1u) / (uint32_t)PB_BAND;
+  const uint32_t per = (bands + 1023u) / 1024u;
+  const uint32_t b0 = t * per, b1 = b0 + per < bands ? b0 + per : bands;
   uint32_t cnt = 0;
-  for (uint32_t r = r0; r < r1; r++) cnt += pbCutRow(cellS, sortedKeys, GX, GY, r, budget, [](uint32_t, uint32_t) {});
+  for (uint32_t b = b0; b < b1; b++) cnt += pbCutBand(cellS, GX, GY, b, budget, [](const PbTile &) {});
   part[t] = cnt;
   __syncthreads();
   for (uint32_t d = 1; d < 1024u; d <<= 1) {
@@ -355,14 +421,14 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict
     __syncthreads();
   }
   uint32_t at = part[t] - cnt;
-  for (uint32_t r = r0; r < r1; r++)
-    (void)pbCutRow(cellS, sortedKeys, GX, GY, r, budget, [&](uint32_t a, uint32_t c) {
-      if (at < maxTiles) tiles[at] = PbTile{a, c};
+  for (uint32_t b = b0; b < b1; b++)
+    (void)pbCutBand(cellS, GX, GY, b, budget, [&](const PbTile &tile) {
+      if (at < maxTiles) tiles[at] = tile;
       at++;
     });
   if (t == 1023u) {
-    ntilesOut[0] = part[1023] < maxTiles ? part[1023] : maxTiles;
-    ntilesOut[1] = 0u;  // workgroups that walked global memory since this layout was cut (statistics)
+    ntilesOut[0] = part[1023];  // (the host refuses a count above maxTiles: launchPatch)
+    ntilesOut[1] = 0u;          // workgroups that walked global memory since this layout was cut (statistics)
   }
 }
 
@@ -388,8 +454,14 @@ __global__ __launch_bounds__(TILE) void k_force_patch(const PbDevParams *__restr
   if ((blockIdx.x >> 3) >= perXcd || tile >= ntiles) return;
   const PbTile T = tiles[tile];
   const uint32_t tid = threadIdx.x;
-  const bool active = tid < T.count;
-  const uint32_t s = T.start + (active ? tid : T.count - 1u);  // idle lanes shadow the tile's last bot (no stores)
+  const uint32_t count = T.cum[PB_BAND - 1];
+  const bool active = tid < count;
+  // lane -> (band row, slot): the tile's bots are PB_BAND slot runs, one per band row; idle lanes shadow the tile's
+  // last bot (they take part in the staging and store nothing)
+  const uint32_t l = active ? tid : count - 1u;
+  uint32_t s = T.start[0] + l;
+#pragma unroll
+  for (int j = 1; j < PB_BAND; j++) s = l >= T.cum[j - 1] ? T.start[j] + (l - T.cum[j - 1]) : s;
 
   const float4 me = prIn[s];
   const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
@@ -547,7 +619,7 @@ __global__ __launch_bounds__(TILE) void k_force_patch(const PbDevParams *__restr
         const int dl = rowDelta[pr];
         lo = (uint32_t)((int)cellS[row + (uint32_t)(gx - 2)] + dl) * 16u;
         hi = (uint32_t)((int)cellS[row + (uint32_t)(gx + 3)] + dl) * 16u;
-        tag = (uint32_t)pr << 13;
+        tag = (uint32_t)pr << PB_PATCH_TAG_SHIFT;
         self = (uint32_t)((int)s + dl) * 16u;
       }
     };
@@ -574,7 +646,7 @@ __global__ __launch_bounds__(TILE) void k_force_patch(const PbDevParams *__restr
         auto push = [&](const float4 &q) __attribute__((always_inline)) {
           if (off != selfOff) {
             if (cnt < (uint32_t)PB_PATCH_CAP) contacts[cnt][tid] = (uint16_t)((off >> 4) | tag);
-            else contactOf((off >> 4) - (uint32_t)rowDelta[tag >> 13], q);
+            else contactOf((off >> 4) - (uint32_t)rowDelta[tag >> PB_PATCH_TAG_SHIFT], q);
             cnt++;
           }
         };
@@ -593,8 +665,8 @@ __global__ __launch_bounds__(TILE) void k_force_patch(const PbDevParams *__restr
     }
     const uint32_t listed = cnt < (uint32_t)PB_PATCH_CAP ? cnt : (uint32_t)PB_PATCH_CAP;
     for (uint32_t k = 0; k < listed; k++) {
-      const uint32_t e = contacts[k][tid], li = e & 0x1fffu;
-      contactOf(li - (uint32_t)rowDelta[e >> 13], patch[li]);
+      const uint32_t e = contacts[k][tid], li = e & ((1u << PB_PATCH_TAG_SHIFT) - 1u);
+      contactOf(li - (uint32_t)rowDelta[e >> PB_PATCH_TAG_SHIFT], patch[li]);
     }
   } else {
     // ---- the tile's box does not fit the patch: walk global memory (x-wrap: two ranges per row); the contact
@@ -646,23 +718,24 @@ __global__ __launch_bounds__(TILE) void k_force_patch(const PbDevParams *__restr
 // stream form 1 (pbSimSetStreamForm): one arena, the LDS-patch kernel over row-aligned tiles
 static bool launchPatch(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext) {
   const uint32_t GX = S->hP[0].gridX, GY = S->hP[0].gridY;
-  // upper bound of the tile count: width-limited tiles hold >= ~budget/13 slots unless their row ends (a tile's
-  // neighbourhood is at most 5 rows x (its own cells + 4)); 3 n / TILE + one per row is never reached in practice
-  const uint32_t maxTiles = 3u * cdiv(S->n, TILE) + GY + 8u;
+  // room for the tile table: a closed tile is followed by a column that did not fit, so two consecutive tiles of a
+  // band hold more than TILE bots between them unless the slot budget cut them short; oversized columns cost extra
+  const uint32_t maxTiles = 4u * cdiv(S->n, TILE) + 2u * cdiv(GY, PB_BAND) + 64u;
   if (!S->tiles) {
     if (hipMalloc(&S->tiles, sizeof(PbTile) * (size_t)maxTiles) != hipSuccess) return false;
     if (hipMalloc(&S->ntiles, 4 * sizeof(uint32_t)) != hipSuccess) return false;
     S->tilesEpoch = ~0ull;
   }
-  if (S->tilesEpoch != S->layoutEpoch) {  // the slot layout changed (re-sort, restored layout): cut the rows anew
-    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), 0, S->stream, S->cellS, S->sortedKeys, GX, GY, S->tiles,
-                       S->ntiles, maxTiles, (uint32_t)PB_PATCH_SLOTS - 160u);
+  if (S->tilesEpoch != S->layoutEpoch) {  // the slot layout changed (re-sort, restored layout): cut the bands anew
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), 0, S->stream, S->cellS, GX, GY, S->tiles, S->ntiles, maxTiles,
+                       (uint32_t)PB_PATCH_BUDGET);
     // the launch grid needs the count on the host: one 4-byte read-back per re-sort (every 18 000 steps)
     if (hipMemcpyAsync(&S->tilesHost, S->ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream) != hipSuccess ||
         hipStreamSynchronize(S->stream) != hipSuccess)
       return false;
     S->tilesEpoch = S->layoutEpoch;
   }
+  if (S->tilesHost == 0u || S->tilesHost > maxTiles) return false;  // (a layout the table cannot hold: form 0 runs)
   const dim3 grid(8u * cdiv(S->tilesHost, 8u));
   const bool asum = attractionSumsKept(S);
 #define PB_PATCH(PL, AS)                                                                                         \

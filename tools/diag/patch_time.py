@@ -1,5 +1,8 @@
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, bench
+if len(sys.argv) > 1:
+    from particlerobotsimulations_amd import _capi
+    _capi.LIB_DIR = os.path.abspath(sys.argv[1]); _capi.HIP_SO = os.path.join(_capi.LIB_DIR, 'libparticlebot_hip.so'); _capi.HOST_SO = os.path.join(_capi.LIB_DIR, 'libparticlebot_host.so')
 import particlerobotsimulations_amd as pb
 pb.legacy.cudaInit(0, None)
 n=1000000
