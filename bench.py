@@ -232,7 +232,6 @@ def cpu_baseline(n_bots, pitch=LATTICE_PITCH, budget_s=12.0):
                       f"({el:.1f} s); reported, not optimised"}
 
 
-STREAM_FORM = 0        # force variant 3: 0 k_force_stream, 1 k_force_patch (--stream-form)
 HEADLINE_VARIANT = 2   # the exact kernel; --force-variant 3 (profiling the streamlined kernel) is flagged in the line
 
 
@@ -243,8 +242,6 @@ def make_sim(pb, n, pitch, seed, lattice="square"):
     sim.set_force_variant(HEADLINE_VARIANT)   # the exact kernel, whatever the environment says (legs that want 3 set it)
     sim.set_lanes_per_bot(0)
     sim.set_resident(0)
-    if STREAM_FORM and hasattr(sim, "set_stream_form"):
-        sim.set_stream_form(STREAM_FORM)
     pos = square_lattice(n, pitch) if lattice == "square" else hex_lattice(n, np.float32(pitch))
     sim.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
                   phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
@@ -1035,14 +1032,11 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0,
                     help="producer threads per pipeline of the ensemble end-to-end runs (default: the rank's share of "
                          "the usable cores, pbHostGetResources)")
-    ap.add_argument("--stream-form", type=int, default=0, choices=[0, 1],
-                    help="force variant 3 legs: 0 k_force_stream, 1 k_force_patch (one LDS patch per workgroup)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path")
     args = ap.parse_args()
-    global DRY, STREAM_FORM
+    global DRY
     DRY = args.dry_run_device
-    STREAM_FORM = args.stream_form
     # HIP gives a new stream the least-used of GPU_MAX_HW_QUEUES (default 4) hardware queues.  Next to the streams of
     # PyTorch and RCCL (any run with a process group) the two batches of the configs[3] leg -- one stream each, meant
     # to overlap -- landed on ONE queue and serialised: 1.68 s end to end instead of 0.95 (round 3, --force-dist).

@@ -244,15 +244,6 @@ int pbSetMinDistanceMode(int mode);
  * tests/test_sqrt_threshold.py. */
 float pbHostSqrtThreshold(float c);
 
-/* Force variant 3 only: which kernel carries the streamlined arithmetic for a single large arena.  0 (default):
- * k_force_stream, neighbours through the vector-memory path.  1: k_force_patch, every workgroup stages its tile's
- * neighbourhood once into LDS (csrc/pb_stream.hip; batches of several simulations keep form 0).  Same arithmetic and
- * per-lane summation order, same results. */
-int pbSimSetStreamForm(pbSim *sim, int form);
-/* Stream form 1: tiles of the current slot layout, and how many workgroup launches since the layout was cut walked
- * global memory because their neighbourhood did not fit the LDS patch (statistics; synchronises the stream). */
-int pbSimGetStreamStats(pbSim *sim, unsigned *tiles, unsigned *fallback_launches);
-
 /* Force-kernel variant of a simulation: 0 reference-shaped branches, 1 branch-free, 2 branch-free
  * with the fast exact sqrt/division forms (default; falls back to 1 when the simulation's
  * constants are outside their proven domain).  Variants 0-2 give bit-identical results.

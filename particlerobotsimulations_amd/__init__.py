@@ -295,16 +295,6 @@ class Sim:
         arithmetic, opt-in, not bit-identical (include/particlebot_hip.h)."""
         _capi.check(_capi.lib().pbSimSetForceVariant(self._h, int(variant)))
 
-    def set_stream_form(self, form):
-        """force variant 3: 0 k_force_stream (default), 1 k_force_patch (one LDS patch per workgroup)"""
-        _capi.check(_capi.lib().pbSimSetStreamForm(self._h, int(form)))
-
-    def stream_stats(self):
-        """stream form 1: (tiles of the current layout, workgroup launches that fell back to global memory)"""
-        a, b = C.c_uint(), C.c_uint()
-        _capi.check(_capi.lib().pbSimGetStreamStats(self._h, C.byref(a), C.byref(b)))
-        return a.value, b.value
-
     def set_force_sums(self, mode):
         """0 (default): absForce_a only when a member reads it (constrained_contraction); otherwise it
         is a dead value, not computed, and get_state() returns NaN for it.  1: always maintained."""

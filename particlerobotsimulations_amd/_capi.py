@@ -148,8 +148,6 @@ SYMBOLS = {
     "pbSimSetLanesPerBot": (_I, [_VP, _I]),
     "pbSimSetResident": (_I, [_VP, _I]),
     "pbSimGetConfig": (_I, [_VP, C.POINTER(pbSimConfig)]),
-    "pbSimSetStreamForm": (_I, [_VP, _I]),
-    "pbSimGetStreamStats": (_I, [_VP, C.POINTER(_U), C.POINTER(_U)]),
     "pbSimSetForceSums": (_I, [_VP, _I]),
     "pbForceFormCount": (_I, []),
     "pbForceFormGet": (_I, [_I, C.POINTER(pbForceForm)]),

@@ -421,7 +421,6 @@ int resort(pbSim *S) {
   PB_TRY(hipGetLastError());
   S->cur = o;
   S->haveCells = true;
-  S->layoutEpoch++;
   S->sortedKeys = S->keys[where];
   S->stats.resorts++;
   return PB_OK;
@@ -605,8 +604,6 @@ void pbSimDestroy(pbSim *S) {
   (void)hipFree(S->dMinD);
   (void)hipFree(S->stage);
   (void)hipFree(S->comPos);
-  (void)hipFree(S->tiles);
-  (void)hipFree(S->ntiles);
   (void)hipFree(S->comPartial);
   (void)hipFree(S->comOut);
   if (S->hMin) (void)hipHostFree(S->hMin);
@@ -880,7 +877,6 @@ int pbSimSetLayoutOf(pbSim *S, unsigned sim, const unsigned *orig, const unsigne
   PB_TRY(hipStreamSynchronize(S->stream));
   S->sortedKeys = S->keys[0];
   S->haveCells = true;
-  S->layoutEpoch++;
   S->layoutOrig.clear();
   S->layoutKeys.clear();
   S->layoutGiven.clear();
@@ -1029,25 +1025,6 @@ int pbSimGetStats(pbSim *S, pbSimStats *stats) {
 int pbSimSetForceVariant(pbSim *S, int variant) {
   if (!S || variant < 0 || variant > 3) return PB_ERR_ARG;
   S->variant = variant;
-  return PB_OK;
-}
-
-int pbSimSetStreamForm(pbSim *S, int form) {
-  if (!S || form < 0 || form > 1) return PB_ERR_ARG;
-  S->streamForm = form;
-  return PB_OK;
-}
-
-int pbSimGetStreamStats(pbSim *S, unsigned *tiles, unsigned *fallback_launches) {
-  if (!S) return PB_ERR_ARG;
-  unsigned v[2] = {0u, 0u};
-  if (S->ntiles) {
-    useDevice(S);
-    PB_TRY(hipStreamSynchronize(S->stream));
-    PB_TRY(hipMemcpy(v, S->ntiles, sizeof v, hipMemcpyDeviceToHost));
-  }
-  if (tiles) *tiles = v[0];
-  if (fallback_launches) *fallback_launches = v[1];
   return PB_OK;
 }
 

@@ -36,14 +36,6 @@ constexpr int TILE = PB_TILE;
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-#ifndef PB_BAND
-#define PB_BAND 4  // grid rows per tile band of stream form 1 (pb_stream.hip)
-#endif
-struct PbTile {
-  // <= TILE bots filed under a block of cells: one slot run per band row; cum[j] = bots in rows 0..j
-  uint32_t start[PB_BAND], cum[PB_BAND];
-};
-
 struct pbSim {
   std::vector<PbDevParams> hP;  // one parameter block per simulation
   PbDevParams *dP = nullptr;
@@ -63,12 +55,6 @@ struct pbSim {
   int cur = 0;                             // which copy of every array is live
 
   uint32_t *cellS = nullptr;  // nsims x (numCells+1), global slot indices
-  unsigned long long layoutEpoch = 0;  // bumped whenever cellS / the slot order is rebuilt
-  PbTile *tiles = nullptr;             // stream form 1: row-aligned tiles of the current layout, built on the device
-  uint32_t *ntiles = nullptr;
-  uint32_t tilesHost = 0;  // the tile count, read back when the tiles are cut
-  unsigned long long tilesEpoch = ~0ull;
-  int streamForm = 0;  // force variant 3: 0 k_force_stream (global loads), 1 k_force_patch (one LDS patch per workgroup)
   uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *slotOf = nullptr;
   uint32_t *sortedKeys = nullptr;  // keys[0] or keys[1]: composite keys of the slots, as of the last sort
   std::vector<uint32_t> layoutOrig, layoutKeys;  // host staging of pbSimSetLayoutOf
