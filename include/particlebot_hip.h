@@ -234,7 +234,8 @@ int pbSimSetResortEveryStep(pbSim *sim, int on);
  * provided the host libm has powf(x,2) == x*x for every float and a non-decreasing powf(., 0.5f), which
  * pbHostLibmCheck (libparticlebot_host.so; tests/test_libm_pin.py) verifies exhaustively.  1: the reference's own
  * loop on the host over all positions (8 n bytes per simulation): no assumption.  pbSetMinDistanceMode sets the
- * default of batches created afterwards (process-wide). */
+ * default of batches created afterwards (process-wide); the environment variable PB_MIN_DISTANCE_MODE (0 or 1) does the
+ * same for a whole process tree (a batch's own pbSimSetMinDistanceMode still wins). */
 int pbSimSetMinDistanceMode(pbSim *sim, int mode);
 int pbSetMinDistanceMode(int mode);
 

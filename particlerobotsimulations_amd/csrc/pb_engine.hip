@@ -660,6 +660,10 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   pbSim *S = new pbSim();
   (void)hipGetDevice(&S->device);
   S->minDistanceMode = g_minDistanceMode;
+  // a process-wide default that CHILD processes inherit (tests/conftest.py exports it when this host's libm fails the
+  // check, so that the binaries the tests spawn take the reference's host loop too); 0 and 1 only, no other effect
+  if (const char *v = getenv("PB_MIN_DISTANCE_MODE"))
+    if ((v[0] == '0' || v[0] == '1') && v[1] == 0) S->minDistanceMode = v[0] - '0';
   S->host = params[0];
   S->host.x1obs = S->host.x2obs = S->host.y1obs = S->host.y2obs = nullptr;
   S->host.x_cir_obs = S->host.y_cir_obs = S->host.r_cir_obs = nullptr;

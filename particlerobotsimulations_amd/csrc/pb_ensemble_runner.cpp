@@ -18,10 +18,13 @@
 // MASTER_PORT itself, which a launcher's own store may hold; $PB_RENDEZVOUS_PORT overrides; default 127.0.0.1:29417 --
 // to the other ranks, which retry until it listens: nothing left behind on disk, nothing a crashed earlier launch
 // could have left either.  --rendezvous FILE exchanges it through that file instead
-// (written to a temporary name and renamed; taken only if rank 0's process, whose id it carries, is alive).
+// (written to a temporary name and renamed; taken only if it carries this launch's token and rank 0's process, whose id
+// it also carries, is alive: SINGLE HOST ONLY).  MASTER_ADDR may be a host name (getaddrinfo); rank 0 listens on every
+// interface, serves until every rank has acknowledged the id, and gives up after one overall deadline.
 // A rank that fails still takes part in the collectives: an error flag is reduced first, then all ranks leave.
 #include <arpa/inet.h>
 #include <hip/hip_runtime.h>
+#include <netdb.h>
 #include <netinet/in.h>
 #include <rccl/rccl.h>
 #include <signal.h>
@@ -88,8 +91,42 @@ static bool recvAll(int fd, void *p, size_t n) {
   return true;
 }
 
-// rank 0: listen, hand the id to world - 1 peers (each says "PBID" + its rank first)
-static bool serveId(const char *addr, int port, int world, const ncclUniqueId &id, double timeoutSeconds) {
+// MASTER_ADDR may be a dotted quad or a host name (torchrun and SLURM commonly pass names): resolved with
+// getaddrinfo; a name that does not resolve is an error, not a silent fall-back to the loopback.
+static bool resolveV4(const char *addr, int port, sockaddr_in *out) {
+  addrinfo hints{}, *res = nullptr;
+  hints.ai_family = AF_INET;
+  hints.ai_socktype = SOCK_STREAM;
+  char portText[16];
+  snprintf(portText, sizeof portText, "%d", port);
+  const int rc = getaddrinfo(addr, portText, &hints, &res);
+  if (rc != 0 || !res) {
+    fprintf(stderr, "rank %d: cannot resolve MASTER_ADDR '%s': %s\n", g_rank, addr, gai_strerror(rc));
+    return false;
+  }
+  memcpy(out, res->ai_addr, sizeof *out);
+  freeaddrinfo(res);
+  return true;
+}
+
+// The launch token: MASTER_PORT and (when the launcher provides one) its run id, so that a process that is not part
+// of THIS launch cannot mark a rank as served, and a stale rendezvous file of another launch is not taken.
+static uint64_t launchToken() {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const char *t) {
+    for (; t && *t; t++) h = (h ^ (unsigned char)*t) * 1099511628211ull;
+    h = (h ^ 0xffu) * 1099511628211ull;
+  };
+  mix(getenv("MASTER_PORT"));
+  mix(getenv("TORCHELASTIC_RUN_ID"));
+  mix(getenv("SLURM_JOB_ID"));
+  mix(getenv("PB_LAUNCH_TOKEN"));
+  return h;
+}
+
+// rank 0: listen on every interface, hand the id to world - 1 peers (each says "PBID" + its rank + the launch token
+// first) and leave only when each of them HAS it; one overall deadline, however many stray connections come by.
+static bool serveId(int port, int world, const ncclUniqueId &id, double timeoutSeconds) {
   const int ls = socket(AF_INET, SOCK_STREAM, 0);
   if (ls < 0) return false;
   int one = 1;
@@ -97,23 +134,31 @@ static bool serveId(const char *addr, int port, int world, const ncclUniqueId &i
   sockaddr_in sa{};
   sa.sin_family = AF_INET;
   sa.sin_port = htons((uint16_t)port);
-  if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+  sa.sin_addr.s_addr = htonl(INADDR_ANY);
   if (bind(ls, (sockaddr *)&sa, sizeof sa) != 0 || listen(ls, world) != 0) {
     close(ls);
     return false;
   }
-  timeval tv{(time_t)timeoutSeconds, 0};
-  setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+  const auto t0 = std::chrono::steady_clock::now();
+  const uint64_t token = launchToken();
   std::vector<char> served(world, 0);
   int left = world - 1;
   while (left > 0) {
+    const double remaining = timeoutSeconds - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (remaining <= 0) break;
+    timeval tv{(time_t)remaining, (suseconds_t)((remaining - (double)(time_t)remaining) * 1e6)};
+    if (tv.tv_sec == 0 && tv.tv_usec < 1000) tv.tv_usec = 1000;
+    setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
     const int fd = accept(ls, nullptr, nullptr);
-    if (fd < 0) break;  // timed out
-    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
-    char hello[4];
+    if (fd < 0) continue;  // timed out: the deadline test above ends the loop
+    timeval peer{2, 0};    // a connection that says nothing does not hold the others up for long
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &peer, sizeof peer);
+    char hello[4], ack = 0;
     int32_t r = -1;
-    if (recvAll(fd, hello, 4) && memcmp(hello, "PBID", 4) == 0 && recvAll(fd, &r, 4) && r > 0 && r < world &&
-        sendAll(fd, &id, sizeof id) && !served[r]) {
+    uint64_t theirs = 0;
+    if (recvAll(fd, hello, 4) && memcmp(hello, "PBID", 4) == 0 && recvAll(fd, &r, 4) && recvAll(fd, &theirs, 8) &&
+        theirs == token && r > 0 && r < world && sendAll(fd, &id, sizeof id) && recvAll(fd, &ack, 1) && ack == 'K' &&
+        !served[r]) {
       served[r] = 1;
       left--;
     }
@@ -124,17 +169,17 @@ static bool serveId(const char *addr, int port, int world, const ncclUniqueId &i
 }
 
 static bool fetchIdTcp(const char *addr, int port, int rank, ncclUniqueId *id, double timeoutSeconds) {
+  sockaddr_in sa{};
+  if (!resolveV4(addr, port, &sa)) return false;
   const auto t0 = std::chrono::steady_clock::now();
+  const uint64_t token = launchToken();
   for (;;) {
     const int fd = socket(AF_INET, SOCK_STREAM, 0);
     if (fd < 0) return false;
-    sockaddr_in sa{};
-    sa.sin_family = AF_INET;
-    sa.sin_port = htons((uint16_t)port);
-    if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
     if (connect(fd, (sockaddr *)&sa, sizeof sa) == 0) {
       const int32_t r = rank;
-      const bool ok = sendAll(fd, "PBID", 4) && sendAll(fd, &r, 4) && recvAll(fd, id, sizeof *id);
+      const bool ok = sendAll(fd, "PBID", 4) && sendAll(fd, &r, 4) && sendAll(fd, &token, 8) &&
+                      recvAll(fd, id, sizeof *id) && sendAll(fd, "K", 1);
       close(fd);
       if (ok) return true;
     } else {
@@ -146,9 +191,12 @@ static bool fetchIdTcp(const char *addr, int port, int rank, ncclUniqueId *id, d
 }
 
 // ---- rendezvous through a file (only on request) ------------------------------------------------------------------
+// Single host only (rank 0's pid is tested with kill(pid, 0), which means nothing in another pid namespace); the
+// record also carries the launch token, so a live process with a recycled pid does not make a stale file look current.
 struct IdFile {
   char magic[8];
   int32_t pid;  // rank 0's process: a file whose writer is gone is stale
+  uint64_t token;
   ncclUniqueId id;
 };
 static bool publishId(const std::string &path, const ncclUniqueId &id) {
@@ -157,8 +205,9 @@ static bool publishId(const std::string &path, const ncclUniqueId &id) {
   FILE *f = fopen(tmp.c_str(), "wb");
   if (!f) return false;
   IdFile rec;
-  memcpy(rec.magic, "PBIDF1\0", 8);
+  memcpy(rec.magic, "PBIDF2\0", 8);
   rec.pid = (int32_t)getpid();
+  rec.token = launchToken();
   rec.id = id;
   const bool ok = fwrite(&rec, sizeof rec, 1, f) == 1;
   if (fclose(f) != 0 || !ok) return false;
@@ -169,9 +218,10 @@ static bool fetchIdFile(const std::string &path, ncclUniqueId *id, double timeou
   for (;;) {
     if (FILE *f = fopen(path.c_str(), "rb")) {
       IdFile rec;
-      const bool ok = fread(&rec, sizeof rec, 1, f) == 1 && memcmp(rec.magic, "PBIDF1\0", 8) == 0;
+      const bool ok = fread(&rec, sizeof rec, 1, f) == 1 && memcmp(rec.magic, "PBIDF2\0", 8) == 0;
       fclose(f);
-      if (ok && rec.pid > 0 && (kill(rec.pid, 0) == 0 || errno == EPERM)) {  // its writer is still running
+      if (ok && rec.token == launchToken() && rec.pid > 0 &&
+          (kill(rec.pid, 0) == 0 || errno == EPERM)) {  // this launch's, and its writer is still running
         *id = rec.id;
         return true;
       }
@@ -211,7 +261,7 @@ int main(int argc, char **argv) {
     else {
       fprintf(stderr, "usage: %s <config.cfg> --members M [--seed0 S] [--set NAME VALUE]... [--sweep KEY V1 V2 ...] "
                       "[--out FILE] [--sub-batch B] [--host-threads T] [--checkpoint DIR | --resume DIR] "
-                      "[--rendezvous FILE]\n", argv[0]);
+                      "[--rendezvous FILE (single host)]\n", argv[0]);
       return 2;
     }
   }
@@ -239,7 +289,7 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < sizeof fake; i++) fb[i] = (unsigned char)(i * 7 + 3);
     bool ok;
     if (rank == 0) {
-      ok = rendezvous.empty() ? serveId(addr0 ? addr0 : "127.0.0.1", port0, world, fake, 30.0) : publishId(rendezvous, fake);
+      ok = rendezvous.empty() ? serveId(port0, world, fake, 30.0) : publishId(rendezvous, fake);
       if (ok && !rendezvous.empty()) std::this_thread::sleep_for(std::chrono::milliseconds(1500));  // stay alive for the readers
     } else {
       ncclUniqueId got;
@@ -268,7 +318,7 @@ int main(int argc, char **argv) {
   if (rank == 0) {
     CHECK_NCCL(ncclGetUniqueId(&id));
     if (world > 1) {
-      const bool ok = rendezvous.empty() ? serveId(addr ? addr : "127.0.0.1", port, world, id, 120.0)
+      const bool ok = rendezvous.empty() ? serveId(port, world, id, 120.0)
                                          : publishId(rendezvous, id);
       if (!ok) {
         fprintf(stderr, "rank 0: rendezvous failed (%s)\n",

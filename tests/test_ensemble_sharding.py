@@ -138,7 +138,7 @@ def test_cxx_runner_id_exchange_world_size_3(how, tmp_path):
         # a file from an "earlier launch": right magic, the pid of a process that no longer exists, another id
         dead = subprocess.Popen([sys.executable, "-c", "pass"])
         dead.wait()
-        path.write_bytes(b"PBIDF1\0\0" + int(dead.pid).to_bytes(4, "little") + bytes(128))
+        path.write_bytes(b"PBIDF2\0\0" + int(dead.pid).to_bytes(4, "little") + bytes(4 + 8 + 128))
         extra = ["--rendezvous", str(path)]
     env = lambda r: dict(os.environ, RANK=str(r), WORLD_SIZE="3", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                          PB_RENDEZVOUS_PORT=str(port))
@@ -150,3 +150,44 @@ def test_cxx_runner_id_exchange_world_size_3(how, tmp_path):
     outs = [p.communicate(timeout=60)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert sorted(o.strip() for o in outs) == [f"rendezvous-test rank {r} of 3: ok" for r in range(3)]
+
+
+def test_cxx_runner_rendezvous_by_host_name_with_strays_and_foreign_files(tmp_path):
+    """MASTER_ADDR as a HOST NAME (launchers pass names) resolves; a stray connection that speaks the
+    protocol but is not of this launch (another token) neither gets served as a rank nor shortens anyone's wait; a
+    rendezvous file written by a LIVE process of another launch (another token) is not taken; a name that does not
+    resolve is an error message, not a silent fall-back to the loopback."""
+    import subprocess
+    import sys
+    import time
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "particlerobotsimulations_amd", "bin",
+                       "particlebot_ensemble")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = lambda r, **kw: dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="localhost",
+                               PB_RENDEZVOUS_PORT=str(port), PB_LAUNCH_TOKEN="this-launch", **kw)
+    rank0 = subprocess.Popen([exe, "--rendezvous-test"], env=env(0), stdout=subprocess.PIPE, text=True)
+    time.sleep(0.3)
+    # a stray: right magic, claims to be rank 1, wrong token
+    c = socket.create_connection(("127.0.0.1", port), timeout=5)
+    c.sendall(b"PBID" + (1).to_bytes(4, "little") + bytes(8))
+    time.sleep(0.2)
+    c.close()
+    rank1 = subprocess.Popen([exe, "--rendezvous-test"], env=env(1), stdout=subprocess.PIPE, text=True)
+    outs = [p.communicate(timeout=60)[0] for p in (rank0, rank1)]
+    assert rank0.returncode == 0 and rank1.returncode == 0, outs
+    assert sorted(o.strip() for o in outs) == [f"rendezvous-test rank {r} of 2: ok" for r in range(2)]
+    # file mode: a record of ANOTHER launch whose writer is alive (this very process) is ignored until the deadline
+    path = tmp_path / "id.bin"
+    path.write_bytes(b"PBIDF2\0\0" + int(os.getpid()).to_bytes(4, "little") + bytes(4) + (12345).to_bytes(8, "little")
+                     + bytes(128))
+    t0 = time.time()
+    p = subprocess.run([exe, "--rendezvous-test", "--rendezvous", str(path)], env=env(1), capture_output=True, text=True,
+                       timeout=90)
+    assert p.returncode != 0 and time.time() - t0 > 5
+    # an unresolvable name
+    p = subprocess.run([exe, "--rendezvous-test"], env=dict(env(1), MASTER_ADDR="no-such-host.invalid"),
+                       capture_output=True, text=True, timeout=90)
+    assert p.returncode != 0 and "cannot resolve MASTER_ADDR" in p.stderr
