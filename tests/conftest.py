@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-size runs (tens of seconds each); part of -m gpu, deselect with -m \"gpu and not slow\"")
 
 
 @pytest.fixture(scope="session", autouse=True)

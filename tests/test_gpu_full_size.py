@@ -1,0 +1,119 @@
+"""BASELINE configs[3] and configs[4] at FULL SIZE inside `-m gpu` (until now they ran at full
+size only in bench.py), through the product's own multi-GPU runner bin/particlebot_ensemble (world of one rank, the
+real RCCL gather):
+
+  * configs[3]: examples/example_obstacle.cfg and examples/example_object_transport.cfg, 256 Monte-Carlo seeds each,
+    120 000 timesteps per member (max_time 1200 = 100 actuation cycles), phase noise on;
+  * configs[4]: a 64-member slice of the dead-fraction sweep -- examples/example_dead_cells.cfg at 10^5 bots, light at
+    (-40, 0), 8 dead fractions 0 ... 0.40 x 8 seeds, 12 000 timesteps (10 cycles), the reference's placement rule.
+
+Size-independent properties: every summary row finite, the row count and clock of the reference's dump gate
+(particlebot.cpp:309-310), every member a different blob, progress toward the light declining monotonically with the
+dead fraction (results/cfg5_full_sweep.md); and three randomly chosen members of each run are replayed stand-alone on
+the CPU oracle over their first 300 timesteps: the same rows to 2e-6 (the device reduces the centre of mass in double
+precision; the member's state is bit-identical, tests/test_gpu_baseline_configs.py)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_gpu_baseline_configs import EX, dump_due, oracle_member
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENS = os.path.join(ROOT, "particlerobotsimulations_amd", "bin", "particlebot_ensemble")
+
+
+def run_ensemble(tmp_path, cfg, members, sets, sweep=None, extra=(), port="29441"):
+    out = tmp_path / "rows.bin"
+    cmd = [ENS, EX(cfg), "--members", str(members), "--seed0", "1000", "--out", str(out)]
+    for k, v in sets.items():
+        cmd += ["--set", k, str(v)]
+    if sweep:
+        cmd += ["--sweep", sweep[0]] + [str(v) for v in sweep[1]]
+    cmd += list(extra)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines   # stdout is rank 0's one JSON line
+    info = json.loads(lines[0])
+    rows = np.fromfile(out, np.float32).reshape(members, info["rows_per_member"], 4)
+    return info, rows
+
+
+def expected_row_times(max_time, di, dt=0.01):
+    """the fp32 clock and dump gate of the reference's display() loop (main.cpp:354-361, particlebot.cpp:174-176,309)"""
+    f = np.float32
+    t, out, steps = f(0.0), [], 0
+    while True:
+        if dump_due(t, di):
+            out.append(t)
+        if t > f(max_time):
+            break
+        t = f(t + f(dt))
+        steps += 1
+    return np.array(out, np.float32), steps   # (0.01f > 0.01: the fp32 clock passes 1200 after 119 915 steps)
+
+
+def replay_three_members(orc, rng, cfg, members, over_of, di, rows):
+    """three random members stand-alone on the oracle over their first 300 timesteps"""
+    orc.lib().orc_set_num_threads(orc.usable_cpus())
+    for k in sorted(rng.choice(members, 3, replace=False)):
+        over = dict(over_of(int(k)), max_time=3.0 - 0.005, dump_interval=float(di))  # 300 steps: t = 0 ... 2.99
+        orows, osim = oracle_member(orc, EX(cfg), over, float(di))
+        osim.close()
+        m = len(orows)
+        assert m >= 4, (k, m)
+        assert np.array_equal(orows[:, 0].astype(np.float32), rows[k, :m, 0]), (k, orows[:, 0], rows[k, :m, 0])
+        assert np.abs(orows[:, 1:] - rows[k, :m, 1:]).max() < 2e-6, (k, orows, rows[k, :m])
+
+
+@pytest.mark.parametrize("cfg,bots", [("example_obstacle.cfg", 500), ("example_object_transport.cfg", 201)])
+def test_config4_all_256_seeds_at_full_length(tmp_path, orc, cfg, bots):
+    members, di = 256, 1.0
+    info, rows = run_ensemble(tmp_path, cfg, members, {"max_time": "1200", "dump_interval": di})
+    assert info["members"] == members and info["bots_per_member"] == bots and info["n_gpus"] == 1
+    want_t, want_steps = expected_row_times(1200.0, di)
+    assert info["steps_per_member"] == want_steps and 119000 < want_steps <= 120001
+    assert rows.shape == (members, len(want_t), 4) and len(want_t) >= 1200
+    assert np.isfinite(rows).all()
+    assert all(np.array_equal(rows[k, :, 0], want_t) for k in range(members))   # one clock, the reference's
+    assert len({tuple(np.round(r[0, 1:3], 5)) for r in rows}) == members         # 256 different blobs
+    # every blob moved, on average toward the light (100 actuation cycles)
+    progress = rows[:, 0, 3].astype(np.float64) - rows[:, -1, 3]
+    assert progress.mean() > 0.2 and (progress > 0).mean() > 0.95, (progress.mean(), (progress > 0).mean())
+    assert abs(info["progress_toward_light_mean"] - progress.mean()) < 1e-5
+    print(f"{cfg}: 256 seeds x {info['steps_per_member']} steps in {info['wall_s']:.2f} s "
+          f"({info['particle_steps_per_s']:.3g} particle-steps/s end to end); progress toward the light "
+          f"{progress.mean():.4f} +- {progress.std():.4f}")
+    replay_three_members(orc, np.random.default_rng(7), cfg, members, lambda k: dict(seed=1000 + k), di, rows)
+
+
+def test_config5_slice_64_members_dead_fraction_trend(tmp_path, orc):
+    members, di = 64, 1.0
+    dead = [int(round(0.40 * i / 7 * 100000)) for i in range(8)]   # 0 ... 40 000 of 100 000
+    sets = {"nCells": "100000", "light_x": "-40", "light_y": "0", "max_time": "120", "dump_interval": di}
+    info, rows = run_ensemble(tmp_path, "example_dead_cells.cfg", members, sets, sweep=("nDead", dead),
+                              extra=["--sub-batch", "-1"], port="29443")
+    want_t, want_steps = expected_row_times(120.0, di)
+    assert info["members"] == members and info["bots_per_member"] == 100000
+    assert info["steps_per_member"] == want_steps and 11900 < want_steps <= 12001
+    assert rows.shape == (members, len(want_t), 4) and np.isfinite(rows).all()
+    assert all(np.array_equal(rows[k, :, 0], want_t) for k in range(members))
+    # member k has dead count dead[k % 8] (the runner's --sweep rule) and seed 1000 + k
+    progress = rows[:, 0, 3].astype(np.float64) - rows[:, -1, 3]
+    by_f = np.array([progress[j::8].mean() for j in range(8)])
+    spread = np.array([progress[j::8].std() for j in range(8)])
+    print("dead fraction -> progress toward the light over 120 s (8 seeds each):",
+          ", ".join(f"{d / 1e5:.3f}: {m:.5f} +- {s:.5f}" for d, m, s in zip(dead, by_f, spread)))
+    assert np.all(np.diff(by_f) < 0), by_f                      # monotone decline (results/cfg5_full_sweep.md)
+    assert 0.07 < by_f[0] < 0.10 and by_f[-1] < 0.5 * by_f[0]    # 0.0842 at f = 0 in the full sweep
+    assert np.all(spread < 0.25 * np.abs(np.diff(by_f)).min() + 1e-3)
+    pl = info["pipeline_rank0"]
+    print(f"64 members x 10^5 bots x {info['steps_per_member']} steps in {info['wall_s']:.1f} s; pipeline {pl}")
+    replay_three_members(orc, np.random.default_rng(8), "example_dead_cells.cfg", members,
+                         lambda k: dict(seed=1000 + k, nDead=dead[k % 8], nCells=100000, light_x=-40.0, light_y=0.0),
+                         di, rows)
