@@ -363,6 +363,11 @@ int main(int argc, char **argv) {
   long steps = 0;
   unsigned nbots = 0;
   pbEnsembleTimings tm{};
+  std::string hostRule;
+  {
+    pbHostResources res;
+    if (pbHostGetResources(&res) == 0) hostRule = res.rule;  // how this rank's producer pool was sized (quota, ranks, NUMA)
+  }
   const auto t0 = std::chrono::steady_clock::now();
   if (mine > 0) {
     std::string myCkpt;
@@ -437,12 +442,16 @@ int main(int argc, char **argv) {
            "\"rows_per_member\": %d, \"wall_s\": %.6f, \"sims_per_s\": %.6g, \"particle_steps_per_s\": %.6g, "
            "\"progress_toward_light_mean\": %.9g, \"progress_toward_light_std\": %.9g, "
            "\"pipeline_rank0\": {\"sub_batch\": %d, \"sub_batches\": %d, \"host_threads\": %d, \"placement_cpu_s\": %.4f, "
-           "\"placement_wait_s\": %.4f, \"upload_s\": %.4f, \"device_s\": %.4f}, \"resumed\": %s, "
+           "\"placement_wait_s\": %.4f, \"upload_s\": %.4f, \"device_s\": %.4f, \"pinned_to_gpu_numa_node\": %s, "
+           "\"numa_node\": %d, \"bound\": \"%s\"}, \"host\": \"%s\", \"resumed\": %s, "
            "\"collective\": \"ncclAllGather of %zu floats per rank (RCCL)\"}\n",
            cfgPath.c_str(), members, world, (int)hs[2], (long)hs[3], allRows, wall, members / wall,
            (double)members * hs[2] * hs[3] / wall, mean, sqrt(var > 0 ? var : 0), tm.sub_batch, tm.sub_batches,
-           tm.host_threads, tm.placement_cpu_s, tm.placement_wait_s, tm.upload_s, tm.device_s, resume ? "true" : "false",
-           block);
+           tm.host_threads, tm.placement_cpu_s, tm.placement_wait_s, tm.upload_s, tm.device_s, tm.pinned ? "true" : "false",
+           tm.numa_node,
+           // host-bound: this rank's placement CPU-seconds over its producer threads exceed the device's time
+           tm.placement_cpu_s / (tm.host_threads > 0 ? tm.host_threads : 1) > tm.device_s + tm.upload_s ? "host" : "device",
+           hostRule.c_str(), resume ? "true" : "false", block);
     fflush(jsonOut);
     if (!outPath.empty()) {
       FILE *f = fopen(outPath.c_str(), "wb");

@@ -36,6 +36,49 @@ def kernel_trace(root):
     return agg, meta
 
 
+def code_object_registers():
+    """{short kernel name: (vgpr_count, sgpr_count, LDS bytes, scratch bytes)} from the CODE OBJECTS' own metadata
+    (the .hip_fatbin of every csrc/build/*.o): rocprofv3's VGPR_Count column is the allocation as the dispatch
+    packet encodes it (granules), not the kernel's register count -- an occupancy argument needs the latter."""
+    import subprocess
+    import tempfile
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    llvm = "/opt/rocm/lib/llvm/bin"
+    out = {}
+    for obj in sorted(glob.glob(os.path.join(here, "particlerobotsimulations_amd", "csrc", "build", "*.o"))):
+        if obj.endswith(".host.o"):
+            continue
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                fat, co = os.path.join(td, "fat"), os.path.join(td, "co")
+                subprocess.check_call([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj],
+                                      stderr=subprocess.DEVNULL)
+                subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                                       "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"],
+                                      stderr=subprocess.DEVNULL)
+                notes = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", co], text=True)
+        except Exception:
+            continue
+        cur = {}
+        for line in notes.splitlines():
+            line = line.strip()
+            for key in (".group_segment_fixed_size", ".name", ".private_segment_fixed_size", ".sgpr_count", ".vgpr_count"):
+                if line.startswith(key + ":") or line.startswith("- " + key + ":"):
+                    cur[key] = line.split(":", 1)[1].strip()
+            if ".vgpr_count" in cur and ".name" in cur and ".sgpr_count" in cur:
+                name = cur[".name"]
+                for tool in (f"{llvm}/llvm-cxxfilt", "c++filt"):
+                    try:
+                        name = subprocess.check_output([tool, cur[".name"]], text=True, stderr=subprocess.DEVNULL).strip()
+                        break
+                    except Exception:
+                        pass
+                out[short(name)] = (cur[".vgpr_count"], cur[".sgpr_count"], cur.get(".group_segment_fixed_size", "?"),
+                                    cur.get(".private_segment_fixed_size", "?"))
+                cur = {}
+    return out
+
+
 def pmc(root, sub):
     out = defaultdict(lambda: defaultdict(list))
     for f in find(os.path.join(root, sub), "*counter_collection.csv"):
@@ -78,12 +121,16 @@ def main():
     total = sum(sum(v) for v in agg.values()) or 1
     print(f"# rocprofv3 summary: {os.path.basename(root)}\n")
     print("## kernel trace (`rocprofv3 --kernel-trace --stats`)\n")
-    print("| kernel | calls | total ms | avg us | min us | max us | % | VGPR | SGPR | LDS | grid | wg |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    regs = code_object_registers()
+    print("(VGPR / SGPR / scratch: `.vgpr_count` / `.sgpr_count` / `.private_segment_fixed_size` of the code object "
+          "(csrc/build/*.o); `?` where the object was not found, e.g. runtime copy kernels.  LDS, grid, wg: the trace.)\n")
+    print("| kernel | calls | total ms | avg us | min us | max us | % | VGPR | SGPR | scratch B | LDS | grid | wg |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         m = meta[k]
+        r = regs.get(k, ("?", "?", "?", "?"))
         print(f"| {k} | {len(v)} | {sum(v)/1e6:.3f} | {sum(v)/len(v)/1e3:.2f} | {min(v)/1e3:.2f} | {max(v)/1e3:.2f} | "
-              f"{100*sum(v)/total:.1f} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} |")
+              f"{100*sum(v)/total:.1f} | {r[0]} | {r[1]} | {r[3]} | {m[2]} | {m[3]} | {m[4]} |")
     counters = defaultdict(dict)
     for sub in ("pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write"):
         for k, cs in pmc(root, sub).items():
