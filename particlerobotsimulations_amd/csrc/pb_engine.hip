@@ -404,7 +404,6 @@ inline bool gate(float t, float interval, float dt) {
 }
 
 int resort(pbSim *S) {
-  pbJoinChunks(S);
   const uint32_t n = S->n;
   const int c = S->cur, o = c ^ 1;
   const dim3 g = gridOf(S), b(TILE);
@@ -431,7 +430,6 @@ int resort(pbSim *S) {
 int g_minDistanceMode = 0;
 
 int phaseUpdate(pbSim *S) {
-  pbJoinChunks(S);
   // particlebot.cpp:212-237.  The reference copies every position to the host and takes
   // min_i powf(powf(lx - x_i, 2) + powf(ly - y_i, 2), 0.5f) there (:214-228); max_d is unused.
   //  mode 0 (default): the device reduces min_i (dx*dx + dy*dy) -- 4 bytes back per simulation -- and the host
@@ -524,7 +522,6 @@ int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
         continue;
       }
       const int c = S->cur;
-      pbJoinChunks(S);
       hipLaunchKernelGGL(k_state, gA, b, 0, S->stream, S->dP, S->pr[c], S->vel[c], S->phase[c], S->dead[c],
                          S->absA[c], S->absR[c], n, t, dt, (int)(lightWave && t >= 0));
       S->stats.state_launches++;
@@ -560,7 +557,6 @@ int stepMany(pbSim *S, float dt, float sortInterval, int nsteps, int *done) {
     S->stats.steps++;
     ahead = fuse;
   }
-  pbJoinChunks(S);
   PB_TRY(hipGetLastError());
   if (done) *done = k;
   return PB_OK;
@@ -613,14 +609,6 @@ void pbSimDestroy(pbSim *S) {
   if (S->hMin) (void)hipHostFree(S->hMin);
   if (S->hMinD) (void)hipHostFree(S->hMinD);
   if (S->hCom) (void)hipHostFree(S->hCom);
-  if (S->forkEvent) {  // (chunked-steps experiment)
-    (void)hipEventDestroy(S->forkEvent);
-    for (int i = 0; i < 32; i++) {
-      if (S->cstream[i]) (void)hipStreamDestroy(S->cstream[i]);
-      for (int g = 0; g < 4; g++)
-        if (S->cev[g][i]) (void)hipEventDestroy(S->cev[g][i]);
-    }
-  }
   if (S->ev0) (void)hipEventDestroy(S->ev0);
   if (S->ev1) (void)hipEventDestroy(S->ev1);
   if (S->stream) (void)hipStreamDestroy(S->stream);
@@ -700,11 +688,6 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     if (const char *v = getenv("PB_FORCE_SUMS")) rc |= pbSimSetForceSums(S, atoi(v));
     if (const char *v = getenv("PB_DEBUG_LDS_BYTES")) S->debugLdsBytes = (unsigned)std::min(atol(v), 65536L);
     if (const char *v = getenv("PB_DEBUG_FORCE_BIG")) S->wideOffsets = atoi(v) != 0;
-    if (const char *v = getenv("PB_DEBUG_CHUNKS")) {  // "C" or "C:streams" (experiment, pb_force.hip)
-      S->chunks = std::max(1, std::min(atoi(v), 32));
-      const char *colon = strchr(v, ':');
-      S->chunkStreams = colon ? std::max(1, std::min(atoi(colon + 1), 32)) : std::min(S->chunks, 8);
-    }
     if (rc != PB_OK) {
       pbLastError() = "pbSimCreateBatch: PB_FORCE_VARIANT / PB_LANES_PER_BOT / PB_RESIDENT out of range";
       delete S;

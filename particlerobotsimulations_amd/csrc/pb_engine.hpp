@@ -78,12 +78,6 @@ struct pbSim {
   int resident = 0;     // 0 automatic, 1 never, 2 whenever the simulation fits one workgroup (n <= 1024)
   int lanesPerBot = 0;  // lanes per bot of the per-step force kernel: 0 automatic; 1 (throughput form), 2, 4, 8, 16
   bool wideOffsets = false;  // run the 64-bit-offset throughput sweep on a batch below 2^28 bots (pbSimSelectForceForm, tests)
-  // EXPERIMENT (PB_DEBUG_CHUNKS, pb_force.hip launchForceT): tile-range launches per step on their own streams
-  int chunks = 1, chunkStreams = 8;
-  uint32_t chunkEpoch = 0;
-  hipStream_t cstream[32] = {};
-  hipEvent_t cev[4][32] = {};
-  hipEvent_t forkEvent = nullptr;
   unsigned debugLdsBytes = 0;  // PB_DEBUG_LDS_BYTES under PB_ALLOW_ENV_OVERRIDES=1 (tools/occupancy_sweep.py --lds)
   int rng = 0;          // phase noise: 0 PB-RNG v1 (counter based), 1 cuRAND-compatible XORWOW (pb_xorwow.hpp)
   int minDistanceMode = 0;  // phase update: 0 device min of squares + host root, 1 the reference's host loop (pbSimSetMinDistanceMode)
@@ -117,12 +111,6 @@ PbForcePlan pbForcePlan(const pbSim *S);
 
 // step n's forces + kick into the other copy of posrad/vel; fuse: also step n+1's radius + integration
 void pbLaunchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext);          // pb_force.hip
-// chunked steps in flight on the chunk streams (experiment): order everything after them on the main stream
-static inline void pbJoinChunks(pbSim *S) {
-  if (S->chunkEpoch == 0) return;
-  for (int ch = 0; ch < S->chunks; ch++) (void)hipStreamWaitEvent(S->stream, S->cev[(S->chunkEpoch - 1) & 3u][ch], 0);
-  S->chunkEpoch = 0;
-}
 void pbLaunchForceStream(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext);    // pb_stream.hip
 // m whole timesteps from time t0 in one launch (simulations of <= 1024 bots)
 bool pbResidentWanted(const pbSim *S);                                                                    // pb_resident.hip

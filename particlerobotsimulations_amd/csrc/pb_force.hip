@@ -43,16 +43,12 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
                                                 float *__restrict__ absA, float *__restrict__ absR,
                                                 const uint32_t *__restrict__ orig,
                                                 const uint32_t *__restrict__ cellSAll, uint32_t n, float dt,
-                                                float timeNext, int doRadiusNext, uint32_t perXcd, int fuse, int fastOk,
-                                                uint32_t tileBase, uint32_t tileCount) {
+                                                float timeNext, int doRadiusNext, uint32_t perXcd, int fuse, int fastOk) {
   const PbDevParams &P = params[blockIdx.y];
   // XCD-aware tile order (large simulations): workgroups b, b+8, b+16, ... share an XCD
   // (round-robin dispatch); give each XCD one contiguous eighth of the tiles (gridDim.x = 8*perXcd).
   // perXcd == 0: plain order (small simulations, a handful of tiles each).
-  // tileBase / tileCount: the launch covers tiles [tileBase, tileBase + tileCount) (chunked steps, experiment)
-  const uint32_t rel = perXcd ? (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3) : blockIdx.x;
-  if (rel >= tileCount) return;
-  const uint32_t tile = tileBase + rel;
+  const uint32_t tile = perXcd ? (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3) : blockIdx.x;
   const uint32_t l = tile * (TILE / L) + threadIdx.x / L;  // all L lanes of a group share the bot
   const uint32_t sub = threadIdx.x % L;
 #ifdef PB_TIMELINE
@@ -117,43 +113,10 @@ void launchForceT(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int 
   const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
   constexpr int NB = (FLAT && L == 1 && !BIG && ASUM) ? PB_THROUGHPUT_NB : 1;
   const int fastOk = (S->variant >= 2 && S->fastOk) ? 1 : 0;
-  if (L == 1 && S->chunks > 1 && S->nsims == 1 && tiles >= 64u * (uint32_t)S->chunks) {
-    // EXPERIMENT (PB_DEBUG_CHUNKS=C[:streams], round 2 and 4): the step as C launches of contiguous tile ranges on
-    // their own streams; chunk ch of this step waits for chunks ch-1, ch, ch+1 (cyclic) of the previous step, so the
-    // drain of one step overlaps the ramp of the next.  ONLY VALID while every bot's stencil stays inside those
-    // chunks' slot ranges -- not guaranteed with stale lists and aliased cells: never enabled by the product.
-    const uint32_t C = (uint32_t)S->chunks, per = cdiv(tiles, C), ep = S->chunkEpoch;
-    if (!S->forkEvent) {
-      (void)hipEventCreateWithFlags(&S->forkEvent, hipEventDisableTiming);
-      for (uint32_t i = 0; i < 32u; i++) {
-        (void)hipStreamCreateWithFlags(&S->cstream[i], hipStreamNonBlocking);
-        for (int g = 0; g < 4; g++) (void)hipEventCreateWithFlags(&S->cev[g][i], hipEventDisableTiming);
-      }
-    }
-    if (ep == 0) (void)hipEventRecord(S->forkEvent, S->stream);
-    for (uint32_t ch = 0; ch < C; ch++) {
-      const uint32_t t0 = ch * per, t1 = std::min(tiles, t0 + per);
-      if (t0 >= t1) continue;
-      const uint32_t ct = t1 - t0, pX = cdiv(ct, 8u);
-      hipStream_t st = S->cstream[ch % (uint32_t)S->chunkStreams];
-      if (ep == 0) {
-        (void)hipStreamWaitEvent(st, S->forkEvent, 0);
-      } else {
-        for (int d = -1; d <= 1; d++) (void)hipStreamWaitEvent(st, S->cev[(ep - 1) & 3u][(ch + C + d) % C], 0);
-      }
-      hipLaunchKernelGGL((k_force<PAYLOAD, FLAT, L, NB, BIG, ASUM>), dim3(pX * 8u, 1), dim3(TILE), S->debugLdsBytes, st,
-                         S->dP, S->pr[c], S->vel[c], S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c],
-                         S->orig[c], S->cellS, S->n, dt, tNext, doRadiusNext, pX, (int)fuse, fastOk, t0, ct);
-      (void)hipEventRecord(S->cev[ep & 3u][ch], st);
-    }
-    S->chunkEpoch = ep + 1;
-    return;
-  }
   // (debugLdsBytes: an occupancy experiment -- unused dynamic LDS that only limits workgroups per CU)
   hipLaunchKernelGGL((k_force<PAYLOAD, FLAT, L, NB, BIG, ASUM>), grid, dim3(TILE), S->debugLdsBytes, S->stream, S->dP,
                      S->pr[c], S->vel[c], S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c],
-                     S->orig[c], S->cellS, S->n, dt, tNext, doRadiusNext, perXcd, (int)fuse, fastOk, 0u,
-                     perXcd ? perXcd * 8u : tiles);
+                     S->orig[c], S->cellS, S->n, dt, tNext, doRadiusNext, perXcd, (int)fuse, fastOk);
 }
 
 // ---- the forms table ---------------------------------------------------------------------------
