@@ -35,8 +35,10 @@ PB_DEV void pbFrictionAndKickS(const PbDevParams &P, bool payload, float fx, flo
     friction *= P.frictionFactor;
     gravity *= P.massFactor;
   }
-  const float hold = 2.0f * friction * gravity;
-  if (__builtin_fmaf(vx, vx, vy * vy) < 1e-12f && __builtin_fmaf(fx, fx, fy * fy) < hold * hold) {
+  // the static-friction hold (impl.cuh:809-811) is the other discontinuity of a step (a held bot either stays exactly
+  // still or starts to move): decided exactly as the exact kernels decide it -- uncontracted squared lengths against
+  // the host-computed thresholds that make `x < T` the same predicate as `sqrtf(x) < c` (PbDevParams::holdV2/holdF2)
+  if (pbDot(vx, vy, vx, vy) < P.holdV2 && pbDot(fx, fy, fx, fy) < (payload ? P.holdF2Payload : P.holdF2)) {
     fx = 0.0f;
     fy = 0.0f;
   }
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
     // v_rsq_f32 root (exact root of d2, pbDistUnitFast) for the handful of contacts of a bot: 3 instructions per
     // contact trip, and the error of the contracted dot product is then the only one left, as in an FMA build.
     {
-      const float h = 0.5f * __builtin_amdgcn_rsqf(d2), e = __builtin_fmaf(-g.dist, g.dist, d2);
-      g.dist = __builtin_fmaf(e, h, g.dist);
+      const float s1 = __builtin_amdgcn_rsqf(d2), e = __builtin_fmaf(-g.dist, g.dist, d2);
+      g.dist = __builtin_fmaf(e, 0.5f * s1, g.dist);
     }
     const float reach = me.z + q.z, gap = g.dist - reach;
     bool contact = gap < 0.0f;
