@@ -371,8 +371,8 @@ def fma_bracket_summary():
                 t["p99_worst"] = max(t["p99_worst"], w["p99"])
                 if case["case"] != "cfg3_arena_crop_10k":   # centred on the origin: |COM| ~ 0, relative figure meaningless
                     t["com_rel_worst"] = max(t["com_rel_worst"], w["com_rel"])
-    rate = lambda c: tot[c]["flips"] / max(tot[c]["bot_windows"], 1)
-    bracket = max(rate("fma"), rate("fma_powf"))
+    rate = lambda c: (tot[c]["flips"] / max(tot[c]["bot_windows"], 1)) if c in tot else None
+    bracket = max(r for r in (rate("fma"), rate("fma_powf")) if r is not None)
     return {"flip_rate_streamlined": rate("hip_streamlined"), "flip_rate_fma": rate("fma"),
             "flip_rate_fma_powf": rate("fma_powf"),
             "ratio": (rate("hip_streamlined") / bracket) if bracket > 0 else None,

@@ -4,7 +4,7 @@ tests/test_fma_bracket.py measures how far a contracted build of the oracle's ow
 nvcc's default -fmad=true and __powf make of the reference (/root/reference/Makefile:79-89,
 particlebot_kernel_impl.cuh:586,589) -- drifts from the oracle in teacher-forced 10-step windows.
 Here the GPU's streamlined kernel goes through the SAME windows of the SAME BASELINE.json
-configurations, next to the two bracket builds, and is held to the bracket:
+configurations, next to the FMA build (the + __powf build is in the CPU fixture), and is held to the bracket:
 
   * bulk: median 0-level, 99th percentile <= 1e-6 relative, centre of mass <= 1e-7 relative
     (absolute on the origin-centred lattice) -- the figures the bracket builds reach;
@@ -46,18 +46,19 @@ def _write_results():
         with open(OUT, "w") as f:
             json.dump({"window": fb.WINDOW, "horizon": fb.HORIZON, "rtol": fb.RTOL,
                        "candidates": {"hip_streamlined": "libparticlebot_hip.so, pbSimSetForceVariant(sim, 3)",
-                                      "fma": "oracle/libpb_oracle_fma.so", "fma_powf": "oracle/libpb_oracle_fma_powf.so"},
+                                      "fma": "oracle/libpb_oracle_fma.so"},
                        "summary": {n: fb.summarise(r) for n, r in _results.items()}, "cases": _results}, f, indent=1)
 
 
 @pytest.mark.parametrize("case", list(fb.CASES))
 def test_streamlined_kernel_inside_the_bracket(pb, orc, case):
     orc.lib().orc_set_num_threads(orc.usable_cpus())
-    for v in orc.BRACKET_VARIANTS:
-        orc.variant_lib(v).orc_set_num_threads(orc.usable_cpus())
+    orc.variant_lib("fma").orc_set_num_threads(orc.usable_cpus())
 
     def factory(P):
-        return [fb.HipCandidate(pb, P)] + [fb.OracleCandidate(orc, P, v) for v in orc.BRACKET_VARIANTS]
+        # (the FMA build runs beside the kernel so that both see the same box; the + __powf build adds nothing --
+        #  the same within noise, tests/golden/fma_bracket/oracle_builds.json -- and a third of the oracle's CPU time)
+        return [fb.HipCandidate(pb, P), fb.OracleCandidate(orc, P, "fma")]
 
     res = fb.measure_case(orc, case, factory)
     _results[case] = res
@@ -72,5 +73,4 @@ def test_streamlined_kernel_inside_the_bracket(pb, orc, case):
         assert (w["com_abs"] <= 1e-8) if centred else (w["com_rel"] <= 1e-7), (case, r)
         assert w["max_abs"] <= fb.WINDOW * 2.5e-4, (case, r)
         assert r["break_p99"] is None or r["break_p99"] >= 20, (case, r)
-    worst_bracket = max(bracket["flips_total"], rows["fma_powf"]["flips_total"])
-    assert hip["flips_total"] <= 3 * worst_bracket + 2, (case, hip, bracket)
+    assert hip["flips_total"] <= 3 * bracket["flips_total"] + 2, (case, hip, bracket)
