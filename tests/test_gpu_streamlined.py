@@ -16,9 +16,13 @@ gap = 0 the pair force jumps from the 2.5 N attraction floor to the contact spri
 that differs from the reference's in the last bit -- this kernel, or the reference's own CUDA
 build against a CPU restatement -- occasionally lands a bot on the other side of one, which moves
 that bot by up to one force jump (2.5 N * dt^2 = 2.5e-4 per step it persists).  Measured on
-MI355X over these windows: 99.8-100 % of the bots agree to better than 1e-6 relative (median
-deviation exactly 0), the centre of mass to 1e-6 relative, and 0-5 bots of 3000 per window are one
-flip apart.  The assertions below are exactly that statement."""
+MI355X over these windows: 99.9-100 % of the bots agree to better than 1e-6 relative (median
+deviation exactly 0), the centre of mass to 1e-8 relative, and 0-3 bots of 3000 per window are one
+flip apart.  The assertions below are exactly that statement.  (Round 4: the kernel takes both
+discontinuous decisions -- contact within ~7 ulp of the threshold, the static-friction hold -- as the
+reference takes them; until then 0-5 bots flipped per window and the very first window, from the
+exactly-touching placement, had 5 % of its bots beyond 1e-5.  How the same windows look for an
+FMA-contracted build of the reference's own arithmetic: tests/test_gpu_fma_bracket.py.)"""
 import numpy as np
 import pytest
 
@@ -82,8 +86,8 @@ def test_windows_within_1e5_relative(pb, orc, case):
         flipped = int((dev > RTOL).sum())
         report.append((start, float(np.median(dev)), float(np.quantile(dev, 0.99)), flipped, float(dabs.max())))
         # per-particle positions: all bots but the few threshold flips within 1e-5 relative ...
-        assert flipped <= max(2, n // 200), (case, start, flipped)
-        assert np.quantile(dev, 0.99) <= RTOL and np.median(dev) <= 1e-6, (case, start)
+        assert flipped <= 5, (case, start, flipped)
+        assert np.quantile(dev, 0.99) <= 1e-6 and np.median(dev) <= 1e-7, (case, start)
         # ... and a flipped bot is at most a few force-law jumps away (2.5 N * dt^2 per step)
         assert dabs.max() <= WINDOW * 2.5e-4, (case, start, dabs.max())
         # centre of mass: 1e-5 relative, always
@@ -104,8 +108,10 @@ def test_windows_within_1e5_relative(pb, orc, case):
 def test_first_window_from_the_touching_placement(pb, orc):
     """The placement leaves every bot exactly touching its anchor and at rest: the most degenerate
     state there is (every contact decision is a last-bit question, every bot sits on the static
-    friction threshold).  The streamlined kernel must still give the same blob: centre of mass to
-    1e-5 relative, >= 90 % of the bots to 1e-5, nobody further than a few force jumps."""
+    friction threshold).  With the contact decision taken exactly as the reference takes it (round 4)
+    the streamlined kernel gives the same blob: centre of mass to 1e-7 relative, >= 99.9 % of the bots
+    within 1e-5 (measured: all of them, max |dp| 1.1e-6, four seeds: tests/diag/first_window.py), nobody
+    further than one force jump."""
     P = orc.default_params(nCells=3000, nDead=0, seed=4321, light_x=-3.0, light_y=2.0, phase_std=0.0, max_time=1e9)
     osim = orc.Sim(P, reset=True)
     sp, keep = simparams_from_orc(P)
@@ -120,9 +126,9 @@ def test_first_window_from_the_touching_placement(pb, orc):
     st = gsim.get_state()
     dev = rel_dev(st["pos"], osim.get("pos"))
     dabs = np.linalg.norm(st["pos"].astype(np.float64) - osim.get("pos"), axis=1)
-    assert (dev <= RTOL).mean() >= 0.90 and dabs.max() <= 3 * WINDOW * 2.5e-4
+    assert (dev <= RTOL).mean() >= 0.999 and dabs.max() <= WINDOW * 2.5e-4
     com_g, com_o = st["pos"].astype(np.float64).mean(0), osim.get("pos").astype(np.float64).mean(0)
-    assert np.linalg.norm(com_g - com_o) <= RTOL * np.linalg.norm(com_o)
+    assert np.linalg.norm(com_g - com_o) <= 1e-7 * np.linalg.norm(com_o)
 
 
 def test_small_batches_keep_the_exact_forms(pb, orc):
@@ -170,7 +176,7 @@ def test_large_arena_against_exact_kernel(pb):
     rel = d / np.maximum(np.linalg.norm(a["pos"].astype(np.float64), axis=1), 1.0)
     outliers = int((rel > RTOL).sum())
     print(f"1e6 bots: median |dp| {np.median(d):.3g}, max {d.max():.3g}, bots beyond 1e-5 relative: {outliers}")
-    assert outliers <= n * 1e-4 and d.max() <= 4 * 2.5e-4
+    assert outliers <= 10 and d.max() <= 2.5e-4   # (round 4: max 7.5e-9, no outlier)
     com_a, com_b = a["pos"].astype(np.float64).mean(0), b["pos"].astype(np.float64).mean(0)
     assert np.linalg.norm(com_a - com_b) <= 1e-7
     assert sims[1].stats()["steps"] == 300 + WINDOW
