@@ -109,6 +109,7 @@ def lib():
 
 
 BRACKET_VARIANTS = ("fma", "fma_powf")
+ORDER_VARIANT = "order"  # exact terms, the two-pass kernel's order of additions
 
 
 def variant_lib(name):
@@ -118,7 +119,7 @@ def variant_lib(name):
     of the reference's arithmetic drifts from it (tests/test_fma_bracket.py)."""
     if name in (None, "exact"):
         return lib()
-    if name not in BRACKET_VARIANTS:
+    if name not in BRACKET_VARIANTS + (ORDER_VARIANT,):
         raise ValueError(name)
     if name not in _variants:
         so = os.path.join(_HERE, f"libpb_oracle_{name}.so")
@@ -126,7 +127,7 @@ def variant_lib(name):
         if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < os.path.getmtime(src)):
             subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)], stdout=subprocess.DEVNULL)
         L = _bind(so)
-        want = {"fma": b"fma", "fma_powf": b"fma+powf"}[name]
+        want = {"fma": b"fma", "fma_powf": b"fma+powf", "order": b"order"}[name]
         if L.orc_build_variant() != want:
             raise RuntimeError(f"{so} reports build variant {L.orc_build_variant()!r}, expected {want!r}")
         _variants[name] = L

@@ -30,7 +30,10 @@
  *   -DORC_BRACKET_POWF  additionally x*x -> exp2f(2*log2f(x)) at the two __powf sites (the published
  *                       definition of __powf(x,y) = exp2f(y * __log2f(x)); glibc's exp2f/log2f stand
  *                       in for the hardware approximations, so this is a LOWER bound on its error)
- * The exact build (neither macro) is the oracle; the bracket builds only measure how far a
+ *   -DORC_BRACKET_ORDER the oracle's own terms, bit for bit, added in the order of the product's two-pass tolerance
+ *                       kernel (a bot's contact terms after its last candidate): isolates what the ORDER of fp32
+ *                       additions alone does (tests/test_fma_bracket.py)
+ * The exact build (no macro) is the oracle; the bracket builds only measure how far a
  * legitimately different build of the same source drifts from it (tests/test_fma_bracket.py).
  */
 #if defined(ORC_BRACKET_POWF)
@@ -40,7 +43,9 @@
 #endif
 
 const char *orc_build_variant(void) {
-#if defined(ORC_BRACKET_FMA) && defined(ORC_BRACKET_POWF)
+#if defined(ORC_BRACKET_ORDER)
+  return "order";
+#elif defined(ORC_BRACKET_FMA) && defined(ORC_BRACKET_POWF)
   return "fma+powf";
 #elif defined(ORC_BRACKET_FMA)
   return "fma";
@@ -638,6 +643,10 @@ void orc_collide(const OrcParams *P, float *newVel, float *absForce_a, float *ab
     const uint32_t orig = index[i];
     float fa = 0.0f;
     float fr = 0.0f * absForce_r[orig]; /* impl.cuh:688 (NaN-propagating on purpose) */
+#if defined(ORC_BRACKET_ORDER)
+    float cfx[64], cfy[64], cfr[64];
+    int ncontact = 0;
+#endif
     const int selfPayload = payloadMode && orig == payloadIdx;
 
     for (int y = -2; y <= 2; y++) {
@@ -651,12 +660,46 @@ void orc_collide(const OrcParams *P, float *newVel, float *absForce_a, float *ab
           if (j == i) continue;
           float att2 = 1.0f;
           if (payloadMode && index[j] == payloadIdx) att2 = P->attractionFactor;
+#if defined(ORC_BRACKET_ORDER)
+          /* the order of additions of the product's two-pass tolerance kernel (k_force_stream): a contact's term is
+           * not added where the reference adds it but after the bot's last candidate, contacts among themselves in
+           * the reference's order; every term is the oracle's own, bit for bit */
+          {
+            float tfx = 0.0f, tfy = 0.0f, tfa = 0.0f, tfr = 0.0f;
+            pair_force(P, px, py, sortedPos[2 * j], sortedPos[2 * j + 1], vx, vy, sortedVel[2 * j],
+                       sortedVel[2 * j + 1], rad, sortedRad[j], P->attraction * att2 * att1, &tfx, &tfy, &tfa, &tfr);
+            if (tfr != 0.0f) { /* a contact (a contact whose term is exactly zero can be added anywhere) */
+              if (ncontact < 64) {
+                cfx[ncontact] = tfx;
+                cfy[ncontact] = tfy;
+                cfr[ncontact] = tfr;
+                ncontact++;
+              } else { /* (more than 64 contacts: in place) */
+                fx += tfx;
+                fy += tfy;
+                fr += tfr;
+              }
+            } else {
+              fx += tfx;
+              fy += tfy;
+              fa += tfa;
+            }
+          }
+#else
           pair_force(P, px, py, sortedPos[2 * j], sortedPos[2 * j + 1], vx, vy, sortedVel[2 * j],
                      sortedVel[2 * j + 1], rad, sortedRad[j], P->attraction * att2 * att1, &fx, &fy, &fa,
                      &fr);
+#endif
         }
       }
     }
+#if defined(ORC_BRACKET_ORDER)
+    for (int c = 0; c < ncontact; c++) {
+      fx += cfx[c];
+      fy += cfy[c];
+      fr += cfr[c];
+    }
+#endif
 
     /* circular obstacles, impl.cuh:703-728 */
     for (int k = 0; k < P->n_cir_obstacles; k++) {

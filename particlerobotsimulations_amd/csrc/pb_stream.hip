@@ -179,7 +179,14 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
     const float rx = q.x - me.x, ry = q.y - me.y;
     const float d2 = fmaxf(__builtin_fmaf(rx, rx, ry * ry), 1e-30f);
     const float inv = __builtin_amdgcn_rsqf(d2);                   // 1/dist
-    const float gap = __builtin_fmaf(d2, inv, -(me.z + q.z));      // dist - reach
+    // dist = the CORRECTLY ROUNDED root of d2 (x * rsq(x) + one Newton step: exact for every float of the domain,
+    // pbSelfTest / tools/one_newton_root_test.hip), then gap = dist - reach rounded as the reference rounds it.  Round 4:
+    // with gap = fma(d2, rsq, -reach) the distance was 1 ulp off the reference's in half the pairs, and where the
+    // attraction law is steep (A / gap^2 and the band ramp: ~1.4e4 N per unit of gap below ~0.002) one ulp of 0.2 is
+    // 2e-4 N -- the largest difference to the reference of the whole force sum, and what made this kernel's states
+    // drift from the oracle's 2.4 x as fast as an FMA build of the reference's own arithmetic drifts
+    // (tests/test_gpu_fma_bracket.py: 43 -> 14 flipped bots where the FMA build has 16).  4 instructions per trip.
+    const float y0 = d2 * inv, gap = __builtin_fmaf(__builtin_fmaf(-y0, y0, d2), 0.5f * inv, y0) - (me.z + q.z);
     const float A = PAYLOAD ? attraction0 * q.w * att1 : attraction0;
     float coef = pbFarCoefS(A, gap);
     // gap < near2: one of the two near bands or contact (gap < 0) -- rare: a wave-uniform branch on one ballot

@@ -133,6 +133,23 @@ def test_small_cases_reproduce_the_fixture(orc, fixture, case):
                 assert g["window"]["com_rel"] <= max(4 * w["window"]["com_rel"], 1e-8)
 
 
+def test_the_order_of_additions_alone_flips_nothing(orc):
+    """oracle/libpb_oracle_order.so: the oracle's own terms, bit for bit, with a bot's CONTACT terms added after its
+    last candidate -- the order of additions of the product's two-pass tolerance kernel (k_force_stream).  Over the same
+    teacher-forced windows that order alone moves no bot beyond 1e-5 and leaves the 99th percentile at 1e-8: it is not
+    what separates that kernel from the reference (DESIGN.md section 5 "Round 4, numerics")."""
+    lib = orc.variant_lib("order")
+    assert lib.orc_build_variant() == b"order"
+    assert fma_functions(os.path.join(os.path.dirname(orc.__file__), "libpb_oracle_order.so")) == {}
+    for case in ("cfg1_example_300", "cfg4_obstacle_500", "cfg4_object_transport_201"):
+        res = fb.measure_case(orc, case, lambda P: [fb.OracleCandidate(orc, P, "order")])
+        row = fb.summarise(res)["order"]
+        print(fb.format_rows(res)[0])
+        assert row["flips_total"] == 0 and row["p99_max"] <= 1e-7 and row["max_max"] <= 1e-6, (case, row)
+        # ... but it is not the identity: some bot differs in the last bits
+        assert row["max_max"] > 0.0, case
+
+
 def test_fixture_covers_every_baseline_config(fixture):
     assert set(fixture["cases"]) == set(fb.CASES)
     for name, (_b, epochs, what) in fb.CASES.items():
