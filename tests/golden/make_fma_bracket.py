@@ -25,7 +25,7 @@ import fma_bracket as fb  # noqa: E402
 
 def main():
     def factory(P):
-        return [fb.OracleCandidate(orc, P, v) for v in orc.BRACKET_VARIANTS]
+        return [fb.OracleCandidate(orc, P, v) for v in orc.BRACKET_VARIANTS + (orc.ORDER_VARIANT,)]
 
     names = sys.argv[1:] or list(fb.CASES)
     results = {}
@@ -42,7 +42,9 @@ def main():
         "machine": platform.machine(),
         "teacher": "oracle/libpb_oracle.so (gcc -O2 -ffp-contract=off): the oracle",
         "candidates": {"fma": "oracle/libpb_oracle_fma.so: kernel functions with fp-contract=fast + FMA",
-                       "fma_powf": "oracle/libpb_oracle_fma_powf.so: that + exp2f(2*log2f(x)) at impl.cuh:586,589"},
+                       "fma_powf": "oracle/libpb_oracle_fma_powf.so: that + exp2f(2*log2f(x)) at impl.cuh:586,589",
+                       "order": "oracle/libpb_oracle_order.so: the oracle's own terms, a bot's contact terms added after its "
+                                "last candidate (the order of additions of the product's two-pass tolerance kernel)"},
         "summary": {n: fb.summarise(r) for n, r in results.items()},
         "cases": results,
     }

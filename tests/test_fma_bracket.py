@@ -166,6 +166,10 @@ def test_what_the_bracket_says(fixture):
     flips = bot_windows = 0
     for name, c in fixture["cases"].items():
         for v, recs in c["candidates"].items():
+            if v == "order":
+                # the ORDER of additions alone (exact terms, contacts added last) moves no bot beyond 1e-5, anywhere
+                assert all(r["window"]["flips"] == 0 and r["window"]["p99"] <= 1e-7 for r in recs), (name, recs)
+                continue
             for r in recs:
                 w = r["window"]
                 # 10-step teacher-forced window: the bulk agrees far inside 1e-5 ...
