@@ -232,6 +232,7 @@ def cpu_baseline(n_bots, pitch=LATTICE_PITCH, budget_s=12.0):
                       f"({el:.1f} s); reported, not optimised"}
 
 
+ENSEMBLE_FORCE_VARIANT = None   # --workload ensemble4|5 --force-variant V: the members' pb_force_variant key
 HEADLINE_VARIANT = 2   # the exact kernel; --force-variant 3 (profiling the streamlined kernel) is flagged in the line
 
 
@@ -620,6 +621,8 @@ def ensemble_batches(workload, rank, world, members_per_gpu, members_total=None,
     ids = ensemble.shard(total, rank, world)
     ex = lambda name: os.path.join(ROOT, "examples", name)
     big = {"max_time": max_time, "dump_interval": "6"}
+    if ENSEMBLE_FORCE_VARIANT is not None:
+        big["pb_force_variant"] = str(ENSEMBLE_FORCE_VARIANT)   # (--force-variant with an ensemble workload)
     if workload == "ensemble4":
         return [(ex("example_obstacle.cfg"), big, [f"seed\n{1000 + k}" for k in ids], ids),
                 (ex("example_object_transport.cfg"), big, [f"seed\n{1000 + k}" for k in ids], ids)]
@@ -877,6 +880,11 @@ def run_ensemble_workload(args, rank, world, dist, torch):
                "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "host": host_info()}
         out.update(res)
+        if ENSEMBLE_FORCE_VARIANT is not None:
+            out["headline"] = False
+            out["config"]["force_variant"] = ENSEMBLE_FORCE_VARIANT
+            out["force_variant_note"] = ("pb_force_variant set for every member: 3 = the opt-in tolerance kernel for "
+                                         "batches in the throughput form (not bit-identical; DESIGN.md section 8)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_ensemble(batches, min(args.cpu_seconds, 10.0))
         emit(out)
@@ -1097,6 +1105,9 @@ def main():
         pb.legacy.cudaInit(0, None)  # otherwise torch.cuda.set_device above already chose this rank's GPU
 
     if args.workload != "arena":
+        global ENSEMBLE_FORCE_VARIANT
+        if args.force_variant != 2:
+            ENSEMBLE_FORCE_VARIANT = args.force_variant
         run_ensemble_workload(args, rank, world, dist, torch)
         if dist is not None:
             dist.barrier()

@@ -113,6 +113,10 @@ class Particlebot {
    * states, as curand_setup does at construction (particlebot.cpp:165); call it before the first step. */
   void setRng(int kind);
   int rngKind() const { return rngKindV; }
+  /* Extension (`pb_force_variant` key): the force kernel of the fused engine -- 0/1/2 the exact forms (2 the default),
+   * 3 the opt-in tolerance kernel (not bit-identical; as close to the reference as an FMA-contracted build of its own
+   * arithmetic).  No effect on the Legacy engine. */
+  void setForceVariant(int variant);
   pbSim *engineHandle() { return sim; }
   /* host mirrors in original bot order (valid after reset(); refreshed by getArray/dump) */
   const float *hostPositions() const { return hPos; }

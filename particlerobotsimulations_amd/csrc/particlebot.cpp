@@ -272,6 +272,12 @@ void Particlebot::_initialize() {
   curand_setup(dState, (int)n);
 }
 
+void Particlebot::setForceVariant(int variant) {
+  if (variant < 0) return;  // (-1: the engine's default)
+  if (variant > 3) die("setForceVariant: 0..3");
+  if (engineKind == Engine::Fused && pbSimSetForceVariant(sim, variant) != PB_OK) die("pbSimSetForceVariant");
+}
+
 void Particlebot::setRng(int kind) {
   if (kind != PB_RNG_COUNTER && kind != PB_RNG_XORWOW_CURAND && kind != PB_RNG_XORWOW_ROCRAND) die("setRng: bad kind");
   rngKindV = kind;

@@ -57,6 +57,7 @@ struct pbFlatConfig {
   char video_filename[300];
   float wallHalf;
   int rngKind;  // pb_rng (PB_RNG_*)
+  int forceVariant;  // pb_force_variant (-1: the engine's default)
 };
 
 }  // extern "C"
@@ -151,6 +152,7 @@ void flatten(const PbRunConfig &cfg, pbFlatConfig *o) {
   snprintf(o->video_filename, sizeof(o->video_filename), "%s", cfg.video_filename.c_str());
   o->wallHalf = cfg.wallHalf();
   o->rngKind = cfg.rng_kind;
+  o->forceVariant = cfg.force_variant;
 }
 
 struct HostSim {
@@ -196,6 +198,7 @@ void *pbHostCreate(const char *cfg_path, const char *overrides, int engine) {
   h->bot->setSquareLattice(h->cfg.square_lattice);
   h->bot->setFastBlob(h->cfg.fast_blob);
   h->bot->setRng(h->cfg.rng_kind);
+  h->bot->setForceVariant(h->cfg.force_variant);
   return h;
 }
 
@@ -654,6 +657,7 @@ bool uploadEnsemble(Ensemble *e) {
   const PbRunConfig &c0 = *e->members[0]->cfg;
   if (pbSimCreateBatch(&e->sim, params.data(), nmembers, c0.wallHalf()) != PB_OK) return false;
   if (c0.rng_kind != 0 && pbSimSetRng(e->sim, c0.rng_kind) != PB_OK) return false;
+  if (c0.force_variant >= 0 && pbSimSetForceVariant(e->sim, c0.force_variant) != PB_OK) return false;  // pb_force_variant
   for (int k = 0; k < nmembers; k++) {
     Particlebot *b = e->members[k]->bot;
     if (pbSimSetStateOf(e->sim, (unsigned)k, b->hostPositions(), b->hostVelocities(), b->hostRadii(), b->hostPhases(),

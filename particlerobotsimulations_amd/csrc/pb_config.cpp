@@ -70,6 +70,7 @@ PbRunConfig::PbRunConfig() {
   square_lattice = false;
   fast_blob = false;
   rng_kind = 0;
+  force_variant = -1;
   repoint();
 }
 
@@ -189,6 +190,12 @@ void PbRunConfig::setParam(const std::string &name, const std::string &value) {
     else if (value.rfind("blob", 0) == 0) params.config = CONFIG_BLOB;
     else if (value.rfind("lighttest7", 0) == 0) params.config = CONFIG_LIGHTTEST_7;
     else params.config = CONFIG_RANDOM;
+  }
+  else if (is("pb_force_variant", 16)) {
+    // which force kernel the fused engine runs (include/particlebot_hip.h pbSimSetForceVariant): 0-2 exact, 3 the
+    // opt-in tolerance kernel; anything else keeps the default
+    const long v = l();
+    force_variant = (v >= 0 && v <= 3) ? (int)v : -1;
   }
   else if (is("pb_rng", 6)) {
     // phase-noise generator (include/particlebot_hip.h PB_RNG_*): "curand" = cuRAND-compatible XORWOW

@@ -21,6 +21,8 @@ struct PbRunConfig {
   float hex_spacing;   // 0 -> 2*min_radius (particlebot.cpp:760); lattice pitch of hex / square placement
   bool square_lattice; // pb_placement square
   bool fast_blob;      // pb_placement fastblob: O(N) random blob (Particlebot::placeFastBlob)
+  int force_variant;   // pb_force_variant: -1 (default) the engine's choice = 2, the exact kernels; 0/1/2 exact forms; 3 the opt-in
+                       // tolerance kernel (pbSimSetForceVariant; held to the FMA bracket of the reference's arithmetic)
   int rng_kind;        // pb_rng: PB_RNG_COUNTER ("pbrng", default), PB_RNG_XORWOW_CURAND ("curand"), PB_RNG_XORWOW_ROCRAND ("rocrand")
 
   PbRunConfig();

@@ -138,6 +138,7 @@ int main(int argc, char **argv) {
   sim.setSquareLattice(cfg.square_lattice);
   sim.setFastBlob(cfg.fast_blob);
   sim.setRng(cfg.rng_kind);
+  sim.setForceVariant(cfg.force_variant);
   sim.reset();
   const SimParams &p = sim.getParams();
   const int frameEvery = cfg.video_interval > 0 ? cfg.video_interval : 100;

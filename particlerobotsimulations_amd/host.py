@@ -41,7 +41,7 @@ class FlatConfig(C.Structure):
         ("camera_x", C.c_float), ("camera_y", C.c_float), ("light_radius", C.c_float),
         ("display_interval", C.c_int32), ("video_interval", C.c_int32),
         ("csv_filename", C.c_char * 300), ("video_filename", C.c_char * 300),
-        ("wallHalf", C.c_float), ("rngKind", C.c_int32),
+        ("wallHalf", C.c_float), ("rngKind", C.c_int32), ("forceVariant", C.c_int32),
     ]
 
 

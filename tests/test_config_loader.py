@@ -110,6 +110,17 @@ def test_extension_keys(host):
     assert c.nCells == 1_000_000
 
 
+def test_force_variant_key(host):
+    """`pb_force_variant` (an extension key, tried after every reference key): 0-3 select the fused engine's force
+    kernel, anything else -- and no key at all -- leaves the default (-1: the exact kernels)."""
+    ex = os.path.join(ROOT, "examples", "example.cfg")
+    assert host.load_config(ex).forceVariant == -1
+    for v in (0, 1, 2, 3):
+        assert host.load_config(ex, pb_force_variant=str(v)).forceVariant == v
+    assert host.load_config(ex, pb_force_variant="7").forceVariant == -1
+    assert host.load_config(ex, pb_force_variant="-2").forceVariant == -1
+
+
 def test_private_generator_equals_glibc_rand(host):
     """PbLibcRand (include/particlebot.h) reproduces srand()/rand() of the glibc the reference runs
     on: the placement and the dead-bot draw depend on it bit for bit."""

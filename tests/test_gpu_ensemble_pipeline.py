@@ -82,3 +82,35 @@ def test_placement_is_hidden_behind_stepping():
     print("pipeline timings", tm, "serial would be", serial)
     assert tm["wall_s"] < 1.25 * hidden + 0.3, (tm, hidden, serial)
     assert tm["wall_s"] < 0.9 * serial or min(tm["placement_cpu_s"], tm["device_s"]) < 0.15 * serial, (tm, serial)
+
+
+def test_force_variant_key_reaches_the_batched_engine(orc):
+    """`pb_force_variant 3` in a member's configuration: the batch of a pipelined ensemble runs the opt-in tolerance
+    kernel (throughput form: 4 x 40 000 bots) -- rows within 1e-6 of the exact kernels' rows after 60 steps (they are
+    NOT bit-identical: a different kernel really ran), and the default stays the exact kernels (bit-identical rows
+    between two default runs)."""
+    from particlerobotsimulations_amd import ensemble
+    cfg = EX("example_dead_cells.cfg")
+    members = [f"seed\n{2000 + k}" for k in range(4)]
+    common = {"nCells": "40000", "nDead": "0", "light_x": "-30", "light_y": "0", "max_time": "0.6", "dump_interval": "0.3",
+              "pb_placement": "fastblob", "phase_std": "0"}
+
+    def rows(extra):
+        p = ensemble.PipelinedEnsemble(cfg, members, dict(common, **extra), sub_batch=0, host_threads=2,
+                                       keep_final_states=True)
+        p.run()
+        r, st = p.rows, p.final_states()
+        p.close()
+        return r, st
+    exact, st_exact = rows({})
+    again, _ = rows({})
+    fast, st_fast = rows({"pb_force_variant": "3"})
+    assert np.array_equal(exact.view(np.uint32), again.view(np.uint32))
+    assert exact.shape == fast.shape and np.isfinite(fast).all()
+    assert np.abs(fast[:, :, 1:3].astype(np.float64) - exact[:, :, 1:3]).max() <= 1e-6 * np.abs(exact[:, :, 1:3]).max()
+    differs = any(not np.array_equal(a["pos"].view(np.uint32), b["pos"].view(np.uint32)) for a, b in zip(st_exact, st_fast))
+    assert differs, "pb_force_variant 3 did not change the kernel"
+    for a, b in zip(st_exact, st_fast):
+        d = np.linalg.norm(a["pos"].astype(np.float64) - b["pos"], axis=1)
+        # (60 un-resynchronised steps of a chaotic blob: most bots still agree exactly, the tail has started to drift)
+        assert np.median(d) <= 1e-7 and np.quantile(d, 0.99) <= 1e-3 and d.max() <= 60 * 2.5e-4
