@@ -197,3 +197,21 @@ def test_what_the_bracket_says(fixture):
     assert big["flips_total"] >= 1 and big["first_break_max"] <= 10
     small = fixture["summary"]["cfg1_example_300"]["fma"]
     assert small["flips_total"] == 0 and small["first_break_max"] >= 25
+
+
+def test_gpu_box_record_agrees_with_this_fixture(fixture):
+    """tests/golden/fma_bracket/hip_streamlined.json was written on the GPU box (another CPU, the FMA build compiled
+    there from the same source): its FMA-build statistics must be THIS container's fixture to the last digit -- the
+    bracket is a deterministic function of (source, gcc), not of the machine -- and the record must hold what
+    DESIGN.md section 8 quotes for the product's tolerance kernel."""
+    rec = json.load(open(os.path.join(HERE, "golden", "fma_bracket", "hip_streamlined.json")))
+    assert set(rec["cases"]) == set(fixture["cases"])
+    flips = {"hip_streamlined": 0, "fma": 0}
+    for name, c in rec["cases"].items():
+        assert c["candidates"]["fma"] == fixture["cases"][name]["candidates"]["fma"], name
+        for cand in flips:
+            flips[cand] += sum(r["window"]["flips"] for r in c["candidates"][cand])
+            for r in c["candidates"][cand]:
+                assert r["window"]["median"] <= 1e-7 and r["window"]["p99"] <= 1e-6
+    # the tolerance kernel flips no more bots than the FMA build of the reference's own arithmetic does (+ slack)
+    assert flips["fma"] == 18 and flips["hip_streamlined"] <= 2 * flips["fma"], flips
