@@ -1007,7 +1007,12 @@ void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *com
   // sub_batch -1: one placement round of the producer pool per sub-batch (every producer places one member, so the
   // device never waits for a second round: with 31 producers a 32-member sub-batch is ready after 3.0 s, a
   // 31-member one after 1.6), at most 64 members (host memory: three sub-batches of placed members are alive)
-  const int autoSub = std::min(p->threads, 64);
+  // Round 4: a pool of 12-23 producers (what a 16-CPU quota grants) takes TWO rounds per sub-batch: 15-member sub-batches
+  // of 10^5-bot members step 9 % slower per bot than 30-member ones (every step carries a launch's ramp and drain), which
+  // costs more than the second placement round the first sub-batch then waits for (0.9 s once).  Fewer than 12
+  // producers: such a rank is host-bound for members of this size, the device should start as early as it can.
+  const int rounds = (p->threads >= 12 && p->threads < 24) ? 2 : 1;
+  const int autoSub = std::min(p->threads * rounds, 64);
   p->sub = sub_batch == -1 ? std::min(autoSub, nmembers) : (sub_batch < 1 || sub_batch > nmembers) ? nmembers : sub_batch;
   if (sub_batch == -1 && resume && checkpoint_dir && checkpoint_dir[0]) {
     // a sweep resumed with the automatic size continues with the size it was started with, whatever the number of
