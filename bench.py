@@ -815,8 +815,9 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
         # that the line shows both what the reference's rule costs here and what the device can do.  Every rank takes
         # the same decision: rank 0's verdict is broadcast.
         fast = None
-        if workload == "ensemble5" and not DRY:
-            host_bound = bool(e2e and any(b["bound"] == "host" for b in e2e["bound_rank0"]))
+        if workload == "ensemble5":
+            # (--dry-run-device: no timings, hence never host-bound, but the broadcast below still runs under gloo)
+            host_bound = bool(e2e and e2e.get("bound_rank0") and any(b["bound"] == "host" for b in e2e["bound_rank0"]))
             if dist is not None:
                 flag = torch.tensor([1 if host_bound else 0], dtype=torch.int32, device=dist_device())
                 dist.broadcast(flag, src=0)

@@ -114,3 +114,14 @@ def test_a_rank_that_never_arrives_ends_the_run_with_code_2():
     assert p.returncode == 2, (p.returncode, p.stderr[-2000:])
     assert "rendezvous failed" in p.stderr and time.time() - t0 < 60
     assert p.stdout.strip() == ""
+
+
+def test_two_rank_ensemble5_line_runs_the_host_bound_broadcast():
+    """--workload ensemble5 on two ranks (two 10^5-bot members per GPU, placed for real: a few CPU-seconds): the rank-0
+    verdict `host-bound?` is broadcast to every rank before the optional fastblob re-run; under the dry-run device it
+    is always `no`, but the collective itself must work."""
+    d = one_json_line(run_bench("--gpus", "2", "--workload", "ensemble5", "--members-per-gpu", "2", "--e2e-steps", "20",
+                                "--steps", "10", "--dry-run-device", timeout=900))
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["config"]["members_per_rank"] == [2, 2]
+    assert d["config"]["bots_per_member"] == [100000] and d["end_to_end"]["rows_gathered"] == [[4, 3, 4]]
+    assert "end_to_end_fastblob" not in d
