@@ -115,7 +115,7 @@ typedef struct pbHostResources {
   int numa_cpus;         /* cores of that node this process may run on, 0: unknown */
   int pin_producers;     /* 1: producer threads are pinned to those cores */
   char pci_bus_id[32];
-  char rule[200];        /* the sentence bench.py prints: how host_threads came about */
+  char rule[320];        /* the sentence bench.py prints: how host_threads came about */
 } pbHostResources;
 int pbHostGetResources(pbHostResources *out);
 /* Parses a sysfs cpulist ("0-31,64-95") restricted to the affinity mask; returns the number of cores and, if

@@ -126,7 +126,7 @@ class HostResources(C.Structure):
     _fields_ = [("hardware_threads", C.c_int), ("affinity_cpus", C.c_int), ("cgroup_cpus", C.c_double),
                 ("usable_cpus", C.c_int), ("local_world_size", C.c_int), ("host_threads", C.c_int),
                 ("device", C.c_int), ("numa_node", C.c_int), ("numa_cpus", C.c_int), ("pin_producers", C.c_int),
-                ("pci_bus_id", C.c_char * 32), ("rule", C.c_char * 200)]
+                ("pci_bus_id", C.c_char * 32), ("rule", C.c_char * 320)]
 
 
 def host_resources():

@@ -17,6 +17,15 @@ void pbHostXorwowOutputs(int kind, unsigned long long seed, unsigned sub, unsign
 void pbHostXorwowNormals(int kind, unsigned seed, unsigned nbots, unsigned draws, float *out);
 int pbEnsembleShard(int nmembers, int rank, int world);
 int pbEnsembleAssemble(int nmembers, int world, int rows, const float *gathered, float *out);
+// round 4: host resources, the pipeline's producer pool and its dry-run consumer
+struct pbHostResourcesBlob { char bytes[512]; };
+int pbHostGetResources(pbHostResourcesBlob *out);
+int pbHostParseCpuList(const char *text, int *cpus, int cap);
+void *pbEnsemblePipelineCreate(const char *cfg, const char *common, const char **members, int n, int sub_batch, int host_threads,
+                               int keep);
+int pbEnsemblePipelineDryRun(void *p, int dwell_ms, unsigned long long *checksums, int *max_ahead);
+int pbEnsemblePipelineHostThreads(void *p);
+void pbEnsemblePipelineDestroy(void *p);
 }
 int main(int argc, char **argv) {
   const char *root = argv[1];
@@ -89,6 +98,24 @@ int main(int argc, char **argv) {
   const char *members[] = {"seed\n1", "seed\n2", "seed\n3", "seed\n4", "seed\n5", "seed\n6"};
   void *e = pbEnsembleCreate(path, "max_time\n1", members, 6);
   printf("ensemble without GPU: %s\n", e ? "created?!" : "null (expected)");
+  // host resources (cgroup files, sysfs, affinity) and the producer pool: sized, pinned if sysfs says so, drained
+  {
+    pbHostResourcesBlob res;
+    memset(&res, 0xee, sizeof res);
+    if (pbHostGetResources(&res) != 0) return 1;
+    int cpus[8];
+    (void)pbHostParseCpuList("0-3,8,10-11,4096-5000,,x", cpus, 8);
+    (void)pbHostParseCpuList("", nullptr, 0);
+    for (int sub : {-1, 0, 2}) {
+      void *p = pbEnsemblePipelineCreate(path, "nCells\n40\nmax_time\n1", members, 6, sub, sub == 2 ? 3 : 0, 0);
+      if (!p) { printf("pipeline create failed\n"); return 1; }
+      unsigned long long sums[6];
+      int ahead = 0;
+      if (pbEnsemblePipelineDryRun(p, 1, sums, &ahead) != 0) { printf("dry run failed\n"); return 1; }
+      printf("pipeline sub %d: %d producers, look-ahead %d\n", sub, pbEnsemblePipelineHostThreads(p), ahead);
+      pbEnsemblePipelineDestroy(p);
+    }
+  }
   printf("asan driver done\n");
   return 0;
 }
