@@ -401,6 +401,40 @@ def both_sums_leg(pb, n, pitch, steps, warmup, warm=None):
     return out
 
 
+def host_round_trip_leg(pb, n, pitch, steps=10):
+    """What the boundary costs a caller who does NOT keep the state on the device: pbSimSetState from host buffers
+    (28 B per bot: pos, vel, rad, phase, dead), one step, pbSimGetState into host buffers (36 B per bot: the same
+    plus the two force sums), every step, pageable numpy memory as a ctypes caller has it, buffers reused.  Never `value`: the
+    class keeps the state resident between CSV dumps, as the reference does (particlebot.cpp:383-395 only reads
+    back for dumpParticlebot).  DESIGN.md section 6 quotes this leg."""
+    sim = make_sim(pb, n, pitch, seed=1)
+    sim.step(50)
+    st = sim.get_state()
+    t_all = t_up = t_down = t_step = 0.0
+    for i in range(steps + 2):
+        t0 = time.perf_counter()
+        sim.set_state(pos=st["pos"], vel=st["vel"], rad=st["rad"], phase=st["phase"], dead=st["dead"])
+        sim.synchronize()
+        t1 = time.perf_counter()
+        sim.step(1)
+        sim.synchronize()
+        t2 = time.perf_counter()
+        st = sim.get_state(out=st)  # the caller's buffers are reused: no fresh pages in the timed copies
+        t3 = time.perf_counter()
+        if i >= 2:
+            t_up += t1 - t0
+            t_step += t2 - t1
+            t_down += t3 - t2
+            t_all += t3 - t0
+    sim.close()
+    up_b, down_b = 28 * n, 36 * n
+    return {"value": n * steps / t_all, "unit": "particle-steps/s", "steps": steps,
+            "ms_per_step": 1e3 * t_all / steps, "upload_ms": 1e3 * t_up / steps, "step_ms": 1e3 * t_step / steps,
+            "download_ms": 1e3 * t_down / steps, "upload_GBps": up_b * steps / t_up / 1e9,
+            "download_GBps": down_b * steps / t_down / 1e9, "bytes_per_bot_per_step": 64,
+            "note": "SetState + 1 step + GetState through pageable host buffers every step; never `value`"}
+
+
 class DevicePrewarm:
     """The chip ramps its clocks over the first ~100 ms of load and drops them again when idle
     (measured: the first 20 steps after an idle spell run at 137 us, after 50 ms of the same kind of
@@ -1021,6 +1055,7 @@ def main():
     ap.add_argument("--no-survey-literal", action="store_true")
     ap.add_argument("--no-streamlined", action="store_true")
     ap.add_argument("--no-both-sums", action="store_true")
+    ap.add_argument("--no-host-round-trip", action="store_true")
     ap.add_argument("--no-large-arena", action="store_true")
     ap.add_argument("--no-clock", action="store_true")
     ap.add_argument("--no-blob", action="store_true")
@@ -1279,6 +1314,8 @@ def main():
         if world == 1 and not args.no_survey_literal:
             out["survey_literal_lattice"] = survey_literal(pb, n, args.steps, args.warmup)
         warm.done()
+        if world == 1 and not args.no_host_round_trip and not DRY:
+            out["host_round_trip"] = host_round_trip_leg(pb, n, args.pitch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.pitch, args.cpu_seconds)
         emit(out)

@@ -223,14 +223,20 @@ class Sim:
         a, r = self._in(absForce_a, np.float32, n), self._in(absForce_r, np.float32, n)
         _capi.check(_capi.lib().pbSimSetForcesOf(self._h, 0, _capi.np_ptr(a), _capi.np_ptr(r)), "pbSimSetForcesOf")
 
-    def get_state(self):
+    def get_state(self, out=None):
+        """The state in original bot order.  `out`: a dict returned by an earlier call, whose arrays are then
+        written in place (a caller that reads back often keeps its host buffers: fresh pages cost more than
+        the copy)."""
         n = self.n
-        out = {
-            "pos": np.empty((n, 2), np.float32), "vel": np.empty((n, 2), np.float32),
-            "rad": np.empty(n, np.float32), "phase": np.empty(n, np.float32),
-            "dead": np.empty(n, np.int32), "absForce_a": np.empty(n, np.float32),
-            "absForce_r": np.empty(n, np.float32),
-        }
+        if out is None:
+            out = {
+                "pos": np.empty((n, 2), np.float32), "vel": np.empty((n, 2), np.float32),
+                "rad": np.empty(n, np.float32), "phase": np.empty(n, np.float32),
+                "dead": np.empty(n, np.int32), "absForce_a": np.empty(n, np.float32),
+                "absForce_r": np.empty(n, np.float32),
+            }
+        elif out.get("absForce_a") is None:
+            out["absForce_a"] = np.empty(n, np.float32)
         _capi.check(_capi.lib().pbSimGetState(self._h, *[_capi.np_ptr(out[k]) for k in
                                                          ("pos", "vel", "rad", "phase", "dead",
                                                           "absForce_a", "absForce_r")]), "pbSimGetState")

@@ -111,6 +111,31 @@ def test_fused_equals_stepwise(pb, orc):
     assert a.stats()["fused_launches"] == 1499 and b.stats()["fused_launches"] == 0
 
 
+def test_state_round_trip_through_reused_host_buffers(pb, orc):
+    """get_state(out=...) writes the caller's arrays in place, and a SetState / step / GetState round trip every
+    step (bench.py's host_round_trip leg) walks the oracle's trajectory bit for bit: pbSimSetState writes each
+    bot into the slot it holds, so the stale cell lists (impl.cuh:680) and the re-sort schedule are untouched."""
+    P = orc.default_params(nCells=1500, nDead=0, seed=9, phase_std=0.0, max_time=1e9)
+    osim, g = make_pair(pb, orc, P)
+    dead = np.zeros(P.nCells, np.int32)
+    dead[[3, 700, 1499]] = 1
+    osim.set("dead", dead)
+    g.set_state(dead=dead)
+    st = g.get_state()
+    if st["absForce_a"] is None:
+        g.set_force_sums(1)
+        st = g.get_state()
+    ids = {k: id(v) for k, v in st.items()}
+    for _ in range(40):
+        g.set_state(pos=st["pos"], vel=st["vel"], rad=st["rad"], phase=st["phase"], dead=st["dead"])
+        g.set_forces(st["absForce_a"], st["absForce_r"])
+        g.step(1)
+        st = g.get_state(out=st)
+        assert {k: id(v) for k, v in st.items()} == ids
+    osim.run(40)
+    compare(osim, g, "round trip every step")
+
+
 def test_dead_bots_and_10k(pb, orc):
     """BASELINE config 2b: example_dead_cells.cfg scaled to 10^4 bots, 20 % dead (dead set given to
     both sides; the host-side rand() draw is tested with the Particlebot class)."""

@@ -4,7 +4,7 @@
 # usage: tools/profile.sh <tag> [bench args...]      (PB_PROFILE_VARIANT=3: profile the streamlined kernel)
 set -u
 TAG=${1:-run}; shift || true
-ARGS=${@:---force-variant ${PB_PROFILE_VARIANT:-2} --steps 400 --warmup 100 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg --no-both-sums}
+ARGS=${@:---force-variant ${PB_PROFILE_VARIANT:-2} --steps 400 --warmup 100 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg --no-both-sums --no-host-round-trip}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -31,7 +31,7 @@ cat "$OUT/summary.md"
 if [ "${PB_PROFILE_LARGE:-1}" = "1" ]; then
   OUT=gpurun_out/prof_${TAG}_8m
   mkdir -p "$OUT"
-  ARGS="--bots 8000000 --steps 60 --warmup 20 --prewarm-ms 0 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg --no-both-sums"
+  ARGS="--bots 8000000 --steps 60 --warmup 20 --prewarm-ms 0 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg --no-both-sums --no-host-round-trip"
   run trace --kernel-trace --stats
   run pmc_fetch --pmc FETCH_SIZE
   run pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
