@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <new>
 #include <string>
 
 namespace {
@@ -34,32 +35,90 @@ void die(const char *what) {
 
 // Occupancy lists of the placement grid.  The reference keeps vector<vector<vector<int>>> indexed
 // [x][y] (particlebot.cpp:614-623); the scans only ever ask "is any listed bot closer than 2 r_min",
-// so a chained list per cell is equivalent.  Cells outside the grid (which the reference indexes
+// so any container of a cell's discs is equivalent.  Cells outside the grid (which the reference indexes
 // out of bounds, :689-691) are treated as empty.
+//
+// On top of the lists, placeRandom keeps for every placed disc ("anchor") which directions of its first
+// rings are certainly crowded (RimMask), updated when a disc is added: of i placed discs only ~sqrt(i) have
+// room, and those mostly on one side, so ~99 % of the reference's draws fail -- and are now decided from
+// the mask, without trigonometry or scan, and without changing a single decision.
 struct PlacementGrid {
   uint gx, gy;
   float ox, oy, cx, cy;
-  // one node per placed disc: its position travels with the chain link, so walking a cell's list
-  // touches one cache line per disc (the lists are walked ~100 times per placed disc)
+  // One cache line per cell: positions and numbers of up to five discs filed under it (cells are 2 r_max wide
+  // and discs 2 r_min apart: five is the most a cell of non-overlapping discs holds) and, for anything beyond
+  // that, a chain of overflow nodes.  The scans walk 9 to 25 neighbouring cells per placed disc and per slow
+  // draw: inline entries make those independent loads of adjacent lines instead of a pointer chase per disc.
+  static constexpr int kInline = 5;
+  struct Cell {
+    float x[kInline], y[kInline];
+    int id[kInline];
+    int meta;  // bits 0-2: inline entries in use; bits 3...: 1 + index of the first overflow node, 0 = none
+  };
+  static_assert(sizeof(Cell) == 64, "one line per cell");
   struct Node {
     float x, y;
-    int next;
+    int id, next;  // next: 1 + index, 0 = end
   };
-  std::vector<int> head;
-  std::vector<Node> node;
-  PlacementGrid(const SimParams &p, uint n)
+  Cell *cell;  // calloc'ed: pages of cells nothing is filed under are never touched
+  std::vector<Node> spill, misfiled;  // misfiled: discs filed under a cell other than their position's
+
+  // ---- what is crowded around an anchor ----
+  // A ring (the circle of candidate positions of radius `ring` around an anchor) is cut into 64 sectors, equal
+  // steps of a pseudo-angle (monotone in the angle, no trigonometry).  A disc at distance D from the anchor
+  // blocks the arc |angle - phi| < acos((ring^2 + D^2 - (limit - margin)^2) / (2 ring D)); bit k of the mask says
+  // that sector k lies entirely inside one disc's arc.  Sufficient, never necessary: the margin (0.1 % of the
+  // limit, and never less than a few float ulps of the coordinates involved -- the candidate is computed in float,
+  // x = ax + 2 r cosf(theta) -- so that an arena thousands of units wide cannot make "crowded" optimistic) and the
+  // 1e-6 added to the cosine shrink every arc, and discs only ever get added, so a set bit stays true.
+  // Rings 1 and 2 always (the rejection counter reaches 200, and the ring widens, for every other disc of a large
+  // blob); ring 3 when the blob is large enough for its draws (6 % of all at 10^5 discs) to outweigh the wider
+  // neighbourhood every added disc then has to mark.
+  static constexpr int kSectors = 64, kRings = 3;
+  struct RimMask {
+    unsigned long long m[kRings];
+  };
+  std::vector<RimMask> rim;  // per disc (placeRandom only)
+  int rings = 0;             // rings tracked, <= kRings
+  double ringOf[kRings] = {0, 0, 0}, limit = 0;
+
+  PlacementGrid(const SimParams &p, uint)
       : gx(p.gridSize.x), gy(p.gridSize.y), ox(p.worldOrigin.x), oy(p.worldOrigin.y), cx(p.cellSize.x),
-        cy(p.cellSize.y), head((size_t)p.gridSize.x * p.gridSize.y, -1), node(n) {}
+        cy(p.cellSize.y), cell((Cell *)calloc((size_t)p.gridSize.x * p.gridSize.y, sizeof(Cell))) {
+    if (!cell) throw std::bad_alloc();
+  }
+  ~PlacementGrid() { free(cell); }
+  PlacementGrid(const PlacementGrid &) = delete;
+  PlacementGrid &operator=(const PlacementGrid &) = delete;
+  int rawCol(double x) const { return (int)floor((x - ox) / cx); }
+  int rawRow(double y) const { return (int)floor((y - oy) / cy); }
   int col(float x) const { return ((int)floorf((x - ox) / cx)) & (int)(gx - 1); }
   int row(float y) const { return ((int)floorf((y - oy) / cy)) & (int)(gy - 1); }
-  // bin disc `bot` under the cell of (x, y); (px, py) is where it really is (they differ only for the
+  // file disc `bot` under the cell of (x, y); (px, py) is where it really is (they differ only for the
   // reference's seed disc, particlebot.cpp:635-637)
   void add(int bot, float x, float y, float px, float py) {
-    const size_t c = (size_t)col(x) * gy + (size_t)row(y);
-    node[bot] = Node{px, py, head[c]};
-    head[c] = bot;
+    if (col(x) != col(px) || row(y) != row(py)) misfiled.push_back(Node{px, py, bot, 0});
+    Cell &c = cell[(size_t)col(x) * gy + (size_t)row(y)];
+    const int k = c.meta & 7;
+    if (k < kInline) {
+      c.x[k] = px, c.y[k] = py, c.id[k] = bot;
+      c.meta++;
+    } else {
+      spill.push_back(Node{px, py, bot, c.meta >> 3});
+      c.meta = (int)(spill.size() << 3) | k;
+    }
   }
   void add(int bot, float x, float y) { add(bot, x, y, x, y); }
+  // f(x, y, id) for every disc filed under cell (xg, yg) until it returns true; true if it did
+  template <class F>
+  bool anyIn(int xg, int yg, F f) const {
+    const Cell &c = cell[(size_t)xg * gy + yg];
+    for (int k = 0, m = c.meta & 7; k < m; k++)
+      if (f(c.x[k], c.y[k], c.id[k])) return true;
+    for (int o = c.meta >> 3; o; o = spill[o - 1].next)
+      if (f(spill[o - 1].x, spill[o - 1].y, spill[o - 1].id)) return true;
+    return false;
+  }
   // any listed bot within `limit` of (x,y) in the 3x3 cells around it?
   // The decision is the reference's `length(...) < limit` with its three powf calls; a double
   // precision squared distance settles every pair that is not within 1e-5 (relative) of the limit
@@ -67,74 +126,170 @@ struct PlacementGrid {
   bool crowded(float x, float y, double limit) const {
     const int xc = col(x), yc = row(y);
     const double far2 = limit * limit * (1.0 + 2e-5), near2 = limit * limit * (1.0 - 2e-5);
+    auto close = [&](float bx, float by, int) {
+      const float dx = x - bx, dy = y - by;
+      const double d2 = (double)dx * dx + (double)dy * dy;
+      if (d2 > far2) return false;
+      return d2 < near2 || hostLength(dx, dy) < limit;
+    };
+    // (the candidate's own cell first: that is where a blocker most often is; the answer is an "any")
+    if (anyIn(xc, yc, close)) return true;
     for (int xg = xc - 1; xg <= xc + 1; xg++)
       for (int yg = yc - 1; yg <= yc + 1; yg++) {
-        if (xg < 0 || yg < 0 || xg >= (int)gx || yg >= (int)gy) continue;
-        for (int b = head[(size_t)xg * gy + yg]; b >= 0; b = node[b].next) {
-          const float dx = x - node[b].x, dy = y - node[b].y;
-          const double d2 = (double)dx * dx + (double)dy * dy;
-          if (d2 > far2) continue;
-          if (d2 < near2 || hostLength(dx, dy) < limit) return true;
-        }
+        if (xg < 0 || yg < 0 || xg >= (int)gx || yg >= (int)gy || (xg == xc && yg == yc)) continue;
+        if (anyIn(xg, yg, close)) return true;
       }
     return false;
   }
-  // Is EVERY point of the circle of radius `ring` around (ax, ay) crowded (closer than `limit` to a listed
-  // disc other than the centre's own)?  A sufficient test with a safety margin far above float rounding:
-  // a disc at distance D blocks the arc |angle - phi| < acos((ring^2 + D^2 - (limit - margin)^2) / (2 ring D));
-  // the circle is covered when the arcs' union is.  Discs only ever get added, so "covered" stays true.
-  // Used by placeRandom to skip the trigonometry and the 9-cell scan for anchors buried in the blob
-  // (nearly all of them: only ~sqrt(i) of i placed discs have room) without changing a single decision.
-  bool ringCovered(float ax, float ay, double ring, double limit) const {
-    // (margin: 0.1 % of the limit, and never less than a few float ulps of the coordinates involved -- the
-    //  candidate point is computed in float, x = ax + 2 r cosf(theta) -- so that a generalised arena thousands
-    //  of units wide cannot make "covered" optimistic)
-    const double ulps = 8.0 * 1.1920929e-7 * (fabs((double)ax) + fabs((double)ay) + ring);
-    const double margin = std::max(1e-3 * limit, ulps);
-    if (margin > 0.25 * limit) return false;
-    const double lim = limit - margin, reach = ring + lim;
-    const int xc = col(ax), yc = row(ay);
-    const int span = (int)ceil(reach / (cx < cy ? cx : cy));
-    constexpr int kArcs = 128;  // (more discs than that in reach: the extra arcs are ignored -- conservative)
-    double lo[kArcs], hi[kArcs];
-    int m = 0;
-    for (int xg = xc - span; xg <= xc + span; xg++)
-      for (int yg = yc - span; yg <= yc + span; yg++) {
-        if (xg < 0 || yg < 0 || xg >= (int)gx || yg >= (int)gy) continue;
-        for (int b = head[(size_t)xg * gy + yg]; b >= 0; b = node[b].next) {
-          // A disc filed under a cell other than its position's (the reference bins bot 0, at (5,0), under the
-          // ORIGIN's cell, :635-637) is only seen by the 3x3 crowded test of candidates near the cell it is filed
-          // under, not near where it is: it must not count as cover here (conservative: the anchor is then
-          // simply tested the slow way)
-          if (col(node[b].x) != xg || row(node[b].y) != yg) continue;
-          const double dx = (double)node[b].x - ax, dy = (double)node[b].y - ay;
-          const double D = sqrt(dx * dx + dy * dy);
-          if (D < 1e-9 || D >= reach) continue;  // the centre itself / too far to reach the ring
-          const double c = (ring * ring + D * D - lim * lim) / (2.0 * ring * D);
-          if (c >= 1.0) continue;
-          const double w = (c <= -1.0 ? 3.141592653589793 : acos(c)) - 1e-6;
-          if (w <= 0.0 || m == kArcs) continue;
-          const double phi = atan2(dy, dx);
-          lo[m] = phi - w;
-          hi[m] = phi + w;
-          m++;
-        }
+
+  static double pseudoAngle(double x, double y) {  // [0, 4), increasing with atan2(y, x) taken in [0, 2 pi)
+    const double s = fabs(x) + fabs(y);
+    if (y >= 0.0) return x >= 0.0 ? y / s : 1.0 - x / s;
+    return x < 0.0 ? 2.0 - y / s : 3.0 + x / s;
+  }
+  // the bits of sectors from ... from + count - 1 (modulo kSectors; 0 < count <= kSectors)
+  static unsigned long long sectors(int from, int count) {
+    const unsigned long long run = count >= 64 ? ~0ull : (1ull << count) - 1;
+    const int sh = from & 63;
+    return sh ? run << sh | run >> (64 - sh) : run;
+  }
+  // the arc a disc in direction (ux, uy) (unit vector) at squared distance D2 (iD = 1 / D) blocks on the ring of
+  // radius `ring`: first sector and number of sectors entirely inside it (0: none), -1: the whole ring
+  static int arcSectors(double ux, double uy, double D2, double iD, double ring, double lim, int *from) {
+    // cosine of the arc's half width, raised by 1e-6: the arc shrinks by at least 1e-6 rad at each end
+    const double c = (ring * ring - lim * lim + D2) * (0.5 / ring) * iD + 1e-6;
+    if (c >= 1.0) return 0;
+    if (c <= -1.0 + 1e-9) return -1;
+    const double sn = sqrt(1.0 - c * c);
+    // the direction turned by -w and by +w, as pseudo-angles
+    const double lo = pseudoAngle(ux * c + uy * sn, uy * c - ux * sn);
+    double hi = pseudoAngle(ux * c - uy * sn, uy * c + ux * sn);
+    if (hi <= lo) hi += 4.0;
+    const int first = (int)ceil(lo * (kSectors / 4.0) + 1e-9), end = (int)floor(hi * (kSectors / 4.0) - 1e-9);
+    *from = first;
+    return end > first ? end - first : 0;
+  }
+  double marginAt(double x, double y) const {
+    const double ulps = 8.0 * 1.1920929e-7 * (fabs(x) + fabs(y) + ringOf[rings - 1]);
+    return std::max(1e-3 * limit, ulps);
+  }
+  bool isMisfiled(float bx, float by) const {
+    for (const Node &o : misfiled)
+      if (o.x == bx && o.y == by) return true;
+    return false;
+  }
+  // placeRandom: radius[k] = radius of ring k + 1, `touch` = the crowding limit, n discs to come
+  void trackRims(uint n, int nrings, const double radius[kRings], double touch) {
+    limit = touch;
+    // the masks speak for the 3x3 scan only if that scan sees every disc within `touch` of a candidate
+    if (cx < touch || cy < touch) return;
+    rim.assign(n, RimMask{});
+    rings = nrings;
+    for (int k = 0; k < nrings; k++) ringOf[k] = radius[k];
+  }
+  // add() for a disc filed where it is, which also marks what it blocks on its neighbours' rings and what they
+  // block on its own.  A disc filed under a cell other than its position's (the reference bins bot 0, at (5,0),
+  // under the ORIGIN's cell, :635-637; a position outside the grid wraps) is only seen by the 3x3 crowded test of
+  // candidates near the cell it is filed under, not near where it is: it neither marks nor is marked
+  // (conservative: draws around it are simply tested the slow way).
+  void addTracked(int bot, float x, float y) {
+    add(bot, x, y);
+    if (rings == 0) return;
+    const double mine = marginAt(x, y), reachMax = ringOf[rings - 1] + limit;
+    const int x0 = rawCol(x - reachMax), x1 = rawCol(x + reachMax), y0 = rawRow(y - reachMax), y1 = rawRow(y + reachMax);
+    // (a disc this close to the edge of the grid -- the reference's blobs never are -- could "block" candidates
+    //  that lie outside it, whose 3x3 scan wraps to the other side: it is left out like a misfiled one)
+    if (x0 < 0 || y0 < 0 || x1 >= (int)gx || y1 >= (int)gy || rawCol(x) != col(x) || rawRow(y) != row(y) ||
+        mine > 0.25 * limit) {
+      misfiled.push_back(Node{x, y, bot, 0});
+      return;
+    }
+    RimMask &me = rim[bot];
+    for (int xg = x0; xg <= x1; xg++)
+      for (int yg = y0; yg <= y1; yg++)
+        anyIn(xg, yg, [&](float bx, float by, int id) {
+          const double dx = (double)bx - x, dy = (double)by - y, D2 = dx * dx + dy * dy;
+          if (id == bot || D2 < 1e-18 || D2 >= reachMax * reachMax) return false;
+          if (!misfiled.empty() && isMisfiled(bx, by)) return false;
+          const double lim = limit - std::max(mine, marginAt(bx, by));
+          if (lim < 0.75 * limit) return false;
+          const double iD = 1.0 / sqrt(D2), ux = dx * iD, uy = dy * iD;  // from the new disc to the neighbour
+          RimMask &other = rim[id];
+          for (int k = 0; k < rings; k++) {
+            const double reach = ringOf[k] + lim;
+            if (D2 >= reach * reach) continue;
+            int from = 0;
+            const int cnt = arcSectors(ux, uy, D2, iD, ringOf[k], lim, &from);
+            if (cnt < 0) {
+              me.m[k] = other.m[k] = ~0ull;
+            } else if (cnt > 0) {
+              me.m[k] |= sectors(from, cnt);
+              other.m[k] |= sectors(from + kSectors / 2, cnt);  // seen from the neighbour: the opposite direction
+            }
+          }
+          return false;
+        });
+  }
+  // the sectors a draw's angle may fall into: theta in 1/65536 of a turn, in steps of 16, two units of slack at
+  // either end; {first sector, count}
+  struct Span {
+    unsigned char first, count;
+  };
+  static const Span *sectorsOfStep() {
+    static Span table[4096];
+    static const bool once = [] {
+      for (int s = 0; s < 4096; s++) {
+        const double a0 = (16.0 * s - 2.0) * (6.283185307179586 / 65536.0), a1 = (16.0 * s + 18.0) * (6.283185307179586 / 65536.0);
+        const int k0 = (int)floor(pseudoAngle(cos(a0), sin(a0)) * (kSectors / 4.0) - 1e-9);
+        const int k1 = (int)floor(pseudoAngle(cos(a1), sin(a1)) * (kSectors / 4.0) + 1e-9);
+        const int cnt = ((k1 - k0) & (kSectors - 1)) + 1;
+        table[s] = Span{(unsigned char)(k0 & (kSectors - 1)), (unsigned char)cnt};
       }
+      return true;
+    }();
+    (void)once;
+    return table;
+  }
+  // is a draw at angle theta (as placeRandom computes it: 2 frand pi, in [0, 2 pi + an ulp]) from anchor `bot` on
+  // ring k + 1 certainly crowded?
+  bool certainlyCrowded(int bot, int k, float theta) const {
+    if (k >= rings) return false;
+    const unsigned long long m = rim[bot].m[k];
+    if (m == ~0ull) return true;  // buried: every direction is
     if (m == 0) return false;
-    // sort by start (tiny insertion sort), then sweep once around from the first arc
-    for (int i = 1; i < m; i++) {
-      const double l = lo[i], h = hi[i];
-      int j = i - 1;
-      for (; j >= 0 && lo[j] > l; j--) lo[j + 1] = lo[j], hi[j + 1] = hi[j];
-      lo[j + 1] = l, hi[j + 1] = h;
-    }
-    double end = hi[0];
-    const double need = lo[0] + 6.283185307179586 + 1e-9;
-    for (int i = 1; i < m && end < need; i++) {
-      if (lo[i] > end) return false;  // a gap
-      if (hi[i] > end) end = hi[i];
-    }
-    return end >= need;
+    const int s = (int)(theta * (65536.0f / 6.2831855f) * (1.0f / 16.0f));
+    if (s < 1 || s >= 4094) return false;  // (the ends of the turn are left to the slow test)
+    const Span sp = sectorsOfStep()[s];
+    const unsigned long long want = sectors(sp.first, sp.count);
+    return (m & want) == want;
+  }
+
+  // Lazy form for the wider rings (rare): is EVERY point of the circle of radius `ring` around (ax, ay)
+  // crowded?  One scan of the discs in reach, same arcs and margins.
+  bool ringCovered(float ax, float ay, double ring, double touch) const {
+    if (cx < touch || cy < touch) return false;
+    const double ulps = 8.0 * 1.1920929e-7 * (fabs((double)ax) + fabs((double)ay) + ring);
+    const double margin = std::max(1e-3 * touch, ulps);
+    if (margin > 0.25 * touch) return false;
+    const double lim = touch - margin, reach = ring + lim;
+    const int x0 = rawCol(ax - reach), x1 = rawCol(ax + reach), y0 = rawRow(ay - reach), y1 = rawRow(ay + reach);
+    if (x0 < 0 || y0 < 0 || x1 >= (int)gx || y1 >= (int)gy) return false;  // (candidates may leave the grid)
+    unsigned long long m = 0;
+    for (int xg = x0; xg <= x1; xg++)
+      for (int yg = y0; yg <= y1; yg++)
+        if (anyIn(xg, yg, [&](float bx, float by, int) {
+              const double dx = (double)bx - ax, dy = (double)by - ay, D2 = dx * dx + dy * dy;
+              if (D2 < 1e-18 || D2 >= reach * reach) return false;  // the centre itself / too far to reach the ring
+              if (col(bx) != xg || row(by) != yg) return false;    // misfiled: no cover (see addTracked)
+              const double iD = 1.0 / sqrt(D2);
+              int from = 0;
+              const int cnt = arcSectors(dx * iD, dy * iD, D2, iD, ring, lim, &from);
+              if (cnt < 0) return true;
+              if (cnt > 0) m |= sectors(from, cnt);
+              return false;
+            }))
+          return true;
+    return m == ~0ull;
   }
 };
 
@@ -683,10 +838,20 @@ void Particlebot::placeRandom() {
   hPos[1] = 0.0;
   grid.add(0, 0.0f, 0.0f, hPos[0], hPos[1]);  // sic: the reference bins bot 0 at the origin's cell (:635-637)
   float x = 0, y = 0;
-  // per anchor: bit k-1 = the whole ring of radius 2 k min_radius around it is crowded
-  // (PlacementGrid::ringCovered; the ring widens with the rejection counter), and consecutive crowded draws
-  // (a coverage test costs ~1 us: an anchor on the rim, which fails often without being buried, is re-tested
-  //  after 4, 8, 16, ... crowded draws)
+  // What is known per anchor (discs only get added, so it stays true):
+  //   rings 1, 2 (3): PlacementGrid::RimMask, kept up to date by addTracked -- a draw into a crowded sector fails
+  //                without trigonometry or scan
+  //   rings ...-8: buried bit k-1 = the whole ring of radius 2 k min_radius is crowded (PlacementGrid::ringCovered,
+  //                run after `retest` failed draws that had to be tested the slow way, then after 2, 4, ... times
+  //                as many).  (The ring widens every 200 rejections; rings beyond the second are rare.)
+  const int kRings = n >= 40000 ? 3 : 2;
+  {
+    double radius[PlacementGrid::kRings];
+    float rr = params.min_radius;  // as the loop below accumulates it
+    for (int k = 0; k < kRings; k++, rr += params.min_radius) radius[k] = 2.0 * (double)rr;
+    grid.trackRims(n, kRings, radius, touch);
+  }
+  const int tracked = grid.rings;  // (0: a grid finer than the discs, nothing is tracked)
   std::vector<unsigned char> buried(n, 0), fails(n, 0), retest(n, 4);
   for (uint i = 1; i < n; i++) {
     if (g_verbosePlacement) printf("Placing %d th disc\n", i);
@@ -702,7 +867,7 @@ void Particlebot::placeRandom() {
       if (x < lowestX) lowestX = x;
       hPos[2 * i] = x;
       hPos[2 * i + 1] = y;
-      grid.add((int)i, x, y);
+      grid.addTracked((int)i, x, y);
       continue;
     }
     float r = params.min_radius;
@@ -714,18 +879,18 @@ void Particlebot::placeRandom() {
         r += params.min_radius;
         level++;
       }
-      if (level <= 8 && (buried[anchor] >> (level - 1) & 1)) {
-        // every direction from this anchor is crowded: the draw of the angle is consumed, the outcome known
-        (void)frand(rng);
+      float theta = 2 * frand(rng) * kPi;
+      if (level <= tracked ? grid.certainlyCrowded((int)anchor, level - 1, theta)
+                          : (level <= 8 && (buried[anchor] >> (level - 1) & 1))) {
+        // the draw of the angle is consumed, the outcome known
         rejections++;
         continue;
       }
-      float theta = 2 * frand(rng) * kPi;
       x = hPos[2 * anchor] + 2 * r * cosf(theta);
       y = hPos[2 * anchor + 1] + 2 * r * sinf(theta);
       if (grid.crowded(x, y, touch)) {
         rejections++;
-        if (level <= 8 && ++fails[anchor] >= retest[anchor]) {
+        if (level > tracked && level <= 8 && ++fails[anchor] >= retest[anchor]) {
           fails[anchor] = 0;
           if (grid.ringCovered(hPos[2 * anchor], hPos[2 * anchor + 1], 2.0 * (double)r, touch))
             buried[anchor] |= (unsigned char)(1u << (level - 1));
@@ -755,7 +920,7 @@ void Particlebot::placeRandom() {
     }
     hPos[2 * i] = x;
     hPos[2 * i + 1] = y;
-    grid.add((int)i, x, y);
+    grid.addTracked((int)i, x, y);
   }
 }
 

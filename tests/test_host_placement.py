@@ -68,12 +68,15 @@ def test_dead_draw_order_statistics_tree_equals_the_erase_loop(host, orc, n, nd)
     assert_bit_equal(dead, o.get("dead"), f"dead set of {nd} among {n}")
 
 
-@pytest.mark.parametrize("cfg,n,seed", [("example_dead_cells.cfg", 30000, 31), ("example_object_transport.cfg", 12001, 32)])
-def test_placement_with_buried_anchor_shortcut_matches_oracle(host, orc, cfg, n, seed):
-    """placeRandom skips the trigonometry and the neighbourhood scan for anchors whose whole ring is provably
-    crowded (PlacementGrid::ringCovered, one flag per ring radius) -- 80 % of the draws at 10^5 bots -- while
-    consuming the same rand() draws; the oracle runs the reference's literal loop.  Same blob, bit for bit,
-    at sizes where the ring has widened many times (the rejection counter passes 200 every few bots)."""
+@pytest.mark.parametrize("cfg,n,seed", [("example_dead_cells.cfg", 30000, 31), ("example_object_transport.cfg", 12001, 32),
+                                        ("example_dead_cells.cfg", 45000, 11), ("example_object_transport.cfg", 40001, 5)])
+def test_placement_with_crowded_sector_shortcut_matches_oracle(host, orc, cfg, n, seed):
+    """placeRandom skips the trigonometry and the neighbourhood scan for draws into directions that are provably
+    crowded (PlacementGrid::RimMask: per placed disc and ring radius, 64 sectors marked as discs are added; rings
+    beyond the tracked ones: PlacementGrid::ringCovered) -- 99 % of the draws at 10^5 bots -- while consuming the
+    same rand() draws; the oracle runs the reference's literal loop.  Same blob, bit for bit, at sizes where the
+    ring has widened many times (the rejection counter passes 200 every few bots) and, from 40 000 bots, with the
+    third ring tracked as well."""
     path = os.path.join(ROOT, "examples", cfg)
     h = host.HostSim(path, engine="host", nCells=str(n), seed=str(seed))
     o = orc.Sim(orc.load_cfg(path, nCells=n, seed=seed), reset=True)
@@ -81,12 +84,16 @@ def test_placement_with_buried_anchor_shortcut_matches_oracle(host, orc, cfg, n,
 
 
 @pytest.mark.parametrize("min_radius,max_radius,n,seed", [(1.0, 1.5, 1200, 8), (1.0, 1.5, 1500, 77), (0.7, 1.0, 2500, 77),
-                                                          (0.2, 0.3, 4000, 77)])
+                                                          (0.2, 0.3, 4000, 77), (0.12, 0.1, 300, 15838),
+                                                          (0.12, 0.1, 3000, 15838)])
 def test_placement_in_a_rescaled_arena_matches_oracle(host, orc, min_radius, max_radius, n, seed):
     """Big discs: once 2 (ring + limit) exceeds 5, an anchor's ring reaches the seed disc, which sits
     at (5,0) but is FILED under the origin's cell (particlebot.cpp:635-637), where the reference's 3x3 crowded
     test only finds it for candidates near the origin.  ringCovered must not count it as cover elsewhere.
-    (The first case is one found by search in which counting it changed the blob from bot 52 on.)"""
+    (The first case is one found by search in which counting it changed the blob from bot 52 on.)
+    The last two have discs WIDER than the grid's cells (min_radius > max_radius): the 3x3 scan then misses
+    blockers two cells away, so nothing may be inferred from a disc's neighbourhood (round 4 found the earlier
+    shortcut wrong there: bot 300-blob of seed 15838)."""
     path = os.path.join(ROOT, "examples", "example.cfg")
     kw = dict(nCells=n, seed=seed, min_radius=min_radius, max_radius=max_radius)
     h = host.HostSim(path, engine="host", **{k: str(v) for k, v in kw.items()})
