@@ -52,16 +52,17 @@ struct PlacementGrid {
   static constexpr int kInline = 5;
   struct Cell {
     float x[kInline], y[kInline];
-    int id[kInline];
-    int meta;  // bits 0-2: inline entries in use; bits 3...: 1 + index of the first overflow node, 0 = none
+    int id[kInline];  // | kNoCover: seen by the 3x3 scan only (see addTracked)
+    int meta;         // bits 0-2: inline entries in use; bits 3...: 1 + index of the first overflow node, 0 = none
   };
+  static constexpr int kNoCover = 1 << 30;
   static_assert(sizeof(Cell) == 64, "one line per cell");
   struct Node {
     float x, y;
     int id, next;  // next: 1 + index, 0 = end
   };
   Cell *cell;  // calloc'ed: pages of cells nothing is filed under are never touched
-  std::vector<Node> spill, misfiled;  // misfiled: discs filed under a cell other than their position's
+  std::vector<Node> spill;
 
   // ---- what is crowded around an anchor ----
   // A ring (the circle of candidate positions of radius `ring` around an anchor) is cut into 64 sectors, equal
@@ -97,7 +98,7 @@ struct PlacementGrid {
   // file disc `bot` under the cell of (x, y); (px, py) is where it really is (they differ only for the
   // reference's seed disc, particlebot.cpp:635-637)
   void add(int bot, float x, float y, float px, float py) {
-    if (col(x) != col(px) || row(y) != row(py)) misfiled.push_back(Node{px, py, bot, 0});
+    if (col(x) != col(px) || row(y) != row(py)) bot |= kNoCover;
     Cell &c = cell[(size_t)col(x) * gy + (size_t)row(y)];
     const int k = c.meta & 7;
     if (k < kInline) {
@@ -173,11 +174,6 @@ struct PlacementGrid {
     const double ulps = 8.0 * 1.1920929e-7 * (fabs(x) + fabs(y) + ringOf[rings - 1]);
     return std::max(1e-3 * limit, ulps);
   }
-  bool isMisfiled(float bx, float by) const {
-    for (const Node &o : misfiled)
-      if (o.x == bx && o.y == by) return true;
-    return false;
-  }
   // placeRandom: radius[k] = radius of ring k + 1, `touch` = the crowding limit, n discs to come
   void trackRims(uint n, int nrings, const double radius[kRings], double touch) {
     limit = touch;
@@ -193,24 +189,21 @@ struct PlacementGrid {
   // candidates near the cell it is filed under, not near where it is: it neither marks nor is marked
   // (conservative: draws around it are simply tested the slow way).
   void addTracked(int bot, float x, float y) {
-    add(bot, x, y);
-    if (rings == 0) return;
+    if (rings == 0) return add(bot, x, y);
     const double mine = marginAt(x, y), reachMax = ringOf[rings - 1] + limit;
     const int x0 = rawCol(x - reachMax), x1 = rawCol(x + reachMax), y0 = rawRow(y - reachMax), y1 = rawRow(y + reachMax);
     // (a disc this close to the edge of the grid -- the reference's blobs never are -- could "block" candidates
     //  that lie outside it, whose 3x3 scan wraps to the other side: it is left out like a misfiled one)
     if (x0 < 0 || y0 < 0 || x1 >= (int)gx || y1 >= (int)gy || rawCol(x) != col(x) || rawRow(y) != row(y) ||
-        mine > 0.25 * limit) {
-      misfiled.push_back(Node{x, y, bot, 0});
-      return;
-    }
+        mine > 0.25 * limit)
+      return add(bot | kNoCover, x, y);
+    add(bot, x, y);
     RimMask &me = rim[bot];
     for (int xg = x0; xg <= x1; xg++)
       for (int yg = y0; yg <= y1; yg++)
         anyIn(xg, yg, [&](float bx, float by, int id) {
           const double dx = (double)bx - x, dy = (double)by - y, D2 = dx * dx + dy * dy;
-          if (id == bot || D2 < 1e-18 || D2 >= reachMax * reachMax) return false;
-          if (!misfiled.empty() && isMisfiled(bx, by)) return false;
+          if (id == bot || id >= kNoCover || D2 < 1e-18 || D2 >= reachMax * reachMax) return false;
           const double lim = limit - std::max(mine, marginAt(bx, by));
           if (lim < 0.75 * limit) return false;
           const double iD = 1.0 / sqrt(D2), ux = dx * iD, uy = dy * iD;  // from the new disc to the neighbour
@@ -277,10 +270,10 @@ struct PlacementGrid {
     unsigned long long m = 0;
     for (int xg = x0; xg <= x1; xg++)
       for (int yg = y0; yg <= y1; yg++)
-        if (anyIn(xg, yg, [&](float bx, float by, int) {
+        if (anyIn(xg, yg, [&](float bx, float by, int id) {
               const double dx = (double)bx - ax, dy = (double)by - ay, D2 = dx * dx + dy * dy;
               if (D2 < 1e-18 || D2 >= reach * reach) return false;  // the centre itself / too far to reach the ring
-              if (col(bx) != xg || row(by) != yg) return false;    // misfiled: no cover (see addTracked)
+              if (id >= kNoCover || col(bx) != xg || row(by) != yg) return false;  // no cover (see addTracked)
               const double iD = 1.0 / sqrt(D2);
               int from = 0;
               const int cnt = arcSectors(dx * iD, dy * iD, D2, iD, ring, lim, &from);
