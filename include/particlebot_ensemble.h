@@ -85,6 +85,9 @@ void pbEnsemblePipelineDestroy(void *pipeline);
 /* producer threads this pipeline started (pbHostResources.host_threads minus one for the device-driving thread when
  * host_threads <= 0 was asked for, at most one per member) */
 int pbEnsemblePipelineHostThreads(void *pipeline);
+/* The size sub_batch -1 stands for: whole placement rounds of the producer pool (1 ... 8) that bring a sub-batch to
+ * ~3 x 10^6 bots (smaller: every step carries a launch's ramp and drain; larger: the state leaves the Infinity Cache). */
+int pbEnsemblePipelineAutoSubBatch(unsigned bots_per_member, int producers);
 unsigned pbEnsemblePipelineNumBots(void *pipeline);
 int pbEnsemblePipelineGetState(void *pipeline, int member, float *pos, float *vel, float *rad);
 /* The consumer side without a device (CPU tests): takes the sub-batches in order as Run does, records a checksum

@@ -984,6 +984,19 @@ long pbEnsembleRun(void *ev, float *out, int max_rows, int *rows) {
 }
 
 // ---- pipelined ensembles (include/particlebot_ensemble.h) ------------------------------------------------------
+// The automatic sub-batch size (sub_batch -1) for members of `bots_per_member` bots and `producers` threads: whole
+// placement rounds of the pool (every producer places one member per round; 1 ... 8 rounds) that bring a sub-batch
+// to ~3 x 10^6 bots.  Measured on BASELINE configs[4] whole (1 024 members of 10^5 bots, 12 000 steps, 15 producers,
+// one MI355X, end to end): sub-batches of 15 / 30 / 45 / 60 / 120 members = 96 / 90.1 / 93.3 / 97.1 / 96.0 s.  Small
+// sub-batches pay a launch's ramp and drain on every step; large ones (> ~200 MB of state) leave the Infinity Cache,
+// which the force kernel's neighbour reads of an evolving blob live on (and the first sub-batch is waited for).
+int pbEnsemblePipelineAutoSubBatch(unsigned bots_per_member, int producers) {
+  const int threads = std::max(producers, 1);
+  const double want = 3.0e6 / (double)std::max(bots_per_member, 1u);
+  const int rounds = std::max(1, std::min(8, (int)(want / threads + 0.5)));
+  return threads * rounds;
+}
+
 void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *common_overrides,
                                            const char **member_overrides, int nmembers, int sub_batch, int host_threads,
                                            int keep_final_states, const char *checkpoint_dir, int resume) {
@@ -1004,15 +1017,19 @@ void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *com
   }
   p->tm.numa_node = res.numa_node;
   p->threads = (int)std::max(1u, std::min<unsigned>(host_threads > 0 ? avail : (avail > 1 ? avail - 1 : 1), (unsigned)nmembers));
-  // sub_batch -1: one placement round of the producer pool per sub-batch (every producer places one member, so the
-  // device never waits for a second round: with 31 producers a 32-member sub-batch is ready after 3.0 s, a
-  // 31-member one after 1.6), at most 64 members (host memory: three sub-batches of placed members are alive)
-  // Round 4: a pool of 12-23 producers (what a 16-CPU quota grants) takes TWO rounds per sub-batch: 15-member sub-batches
-  // of 10^5-bot members step 9 % slower per bot than 30-member ones (every step carries a launch's ramp and drain), which
-  // costs more than the second placement round the first sub-batch then waits for (0.9 s once).  Fewer than 12
-  // producers: such a rank is host-bound for members of this size, the device should start as early as it can.
-  const int rounds = (p->threads >= 12 && p->threads < 24) ? 2 : 1;
-  const int autoSub = std::min(p->threads * rounds, 64);
+  // sub_batch -1: pbEnsemblePipelineAutoSubBatch for members of this size
+  unsigned botsPerMember = 0;
+  {
+    PbRunConfig c0;
+    c0.params.seed = 0;
+    if (!cfg_path || c0.loadFile(cfg_path)) {
+      applyOverrides(c0, common_overrides);
+      applyOverrides(c0, p->over[0].c_str());
+      c0.derive();
+      botsPerMember = c0.params.nCells;
+    }
+  }
+  const int autoSub = pbEnsemblePipelineAutoSubBatch(botsPerMember, p->threads);
   p->sub = sub_batch == -1 ? std::min(autoSub, nmembers) : (sub_batch < 1 || sub_batch > nmembers) ? nmembers : sub_batch;
   if (sub_batch == -1 && resume && checkpoint_dir && checkpoint_dir[0]) {
     // a sweep resumed with the automatic size continues with the size it was started with, whatever the number of

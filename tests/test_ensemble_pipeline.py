@@ -62,14 +62,23 @@ def test_look_ahead_is_bounded():
         assert ahead >= sub          # ... and they do run ahead while the consumer dwells
 
 
-def test_automatic_sub_batch_is_one_placement_round():
-    """sub_batch -1: as many members per sub-batch as there are producer threads (every sub-batch is ready after ONE
-    round of the pool); same members, and the look-ahead bound follows that size."""
+def test_automatic_sub_batch_is_whole_placement_rounds():
+    """sub_batch -1: whole rounds of the producer pool (1 ... 8) that bring a sub-batch to ~3e6 bots; same members,
+    and the look-ahead bound follows that size."""
+    import ctypes as C
+    from particlerobotsimulations_amd import host
+    auto = host.lib().pbEnsemblePipelineAutoSubBatch
+    auto.argtypes, auto.restype = [C.c_uint, C.c_int], C.c_int
+    assert auto(100000, 15) == 30       # BASELINE configs[4] under a 16-CPU quota: 2 rounds (the measured optimum)
+    assert auto(100000, 31) == 31       # ... with 32 CPUs: 1 round
+    assert auto(100000, 1) == 8 and auto(100000, 3) == 24
+    assert auto(1000000, 15) == 15      # big members: one round
+    assert auto(500, 15) == 120 and auto(0, 0) == 8
     ref, _ = _dry(0, 1)
     for threads in (1, 3, 5):
         sums, ahead = _dry(-1, threads, dwell=3)
         assert np.array_equal(sums, ref), threads
-        assert ahead <= 3 * threads, (threads, ahead)
+        assert ahead <= 3 * 8 * threads, (threads, ahead)
 
 
 def test_bad_cfg_fails_cleanly():
