@@ -38,10 +38,10 @@ int pbEnsembleGetState(void *ensemble, int member, float *pos, float *vel, float
 unsigned pbEnsembleNumBots(void *ensemble);
 
 /* ---- pipelined form: host placement overlapped with device stepping --------------------------------------------
- * The placement of a member is host work (the reference's CONFIG_RANDOM rule is O(N^1.5): 1.4 s for a 10^5-bot
- * member; particlebot.cpp:612-748) and pbEnsembleCreate does all of it before the first launch.  The pipeline cuts
- * the rank's members into sub-batches of `sub_batch` members (0, or more than there are: one batch; -1: automatic --
- * whole placement rounds of the producer pool, at most 64 members: one round, or two when the pool has 12-23 threads: for
+ * The placement of a member is host work (the reference's CONFIG_RANDOM rule draws O(N^1.5) candidates: 0.3 to 0.5
+ * CPU-s for a 10^5-bot member; particlebot.cpp:612-748) and pbEnsembleCreate does all of it before the first launch.  The pipeline cuts
+ * the rank's members into sub-batches of `sub_batch` members (0, or more than there are: one batch; -1: automatic,
+ * pbEnsemblePipelineAutoSubBatch below: for
  * members too large to batch all at once, e.g. BASELINE config 5's 10^5-bot members) and builds the members of sub-batch
  * k+1 (k+2, ...) on `host_threads` producer threads (<= 0: the rank's share of the host cores minus one for the
  * thread that drives the device) WHILE the device steps sub-batch k: wall time = max(host, device) + one

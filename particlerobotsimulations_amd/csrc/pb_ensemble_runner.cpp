@@ -9,8 +9,9 @@
 // Launch with any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (torchrun), OMPI_COMM_WORLD_* or
 // SLURM_PROCID / SLURM_NTASKS / SLURM_LOCALID, or by hand:  RANK=r WORLD_SIZE=N LOCAL_RANK=r ...
 // Member k (seed seed0 + k, sweep value V[k mod #V]) runs on rank k mod N.  A rank's members run through the
-// placement/stepping pipeline (pbEnsemblePipeline*): sub-batches of B members (0: all at once, the default; -1: as many
-// as there are producer threads -- for members of ~10^5 bots and more), the host placing the next ones
+// placement/stepping pipeline (pbEnsemblePipeline*): sub-batches of B members (0: all at once, the default; -1: whole
+// placement rounds of the producer pool that bring a sub-batch to ~3 x 10^6 bots -- for members of ~10^5 bots and
+// more), the host placing the next ones
 // while the device steps the current one.  --checkpoint DIR saves every member exactly at each summary row
 // (DIR/rank<r>/...); --resume DIR continues a killed sweep from there (same M, N and B), bit-identically.
 //

@@ -169,7 +169,8 @@ class PipelinedEnsemble:
     """The members this rank runs, cut into sub-batches of `sub_batch` members: the host places sub-batch k+1 on
     `host_threads` producer threads while the device steps sub-batch k (pbEnsemblePipeline* in csrc/pb_capi.cpp).
     Placement starts in the constructor.  Rows and final states do not depend on sub_batch or host_threads.
-    sub_batch 0: all members in one batch; -1: as many as there are producer threads (large members)."""
+    sub_batch 0: all members in one batch; -1: automatic (pbEnsemblePipelineAutoSubBatch: whole placement
+    rounds of the producer pool that bring a sub-batch to ~3e6 bots; for large members)."""
 
     def __init__(self, cfg_path, overrides_per_member, common=None, sub_batch=0, host_threads=0, max_rows=4096,
                  keep_final_states=False, checkpoint_dir=None, resume=False):
