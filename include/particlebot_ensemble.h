@@ -65,6 +65,7 @@ typedef struct pbEnsembleTimings {
   int numa_node;            /* that node, -1 unknown */
   double placement_thread_wall_s; /* wall seconds the producers spent building members (sum over threads): exceeds
                                placement_cpu_s when the threads did not get a core each (oversubscription, quota) */
+  int lanes;                /* sub-batches stepped at the same time; placement_wait_s, upload_s and device_s are per lane */
 } pbEnsembleTimings;
 void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
                                int nmembers, int sub_batch, int host_threads, int keep_final_states);
@@ -85,6 +86,9 @@ void pbEnsemblePipelineDestroy(void *pipeline);
 /* producer threads this pipeline started (pbHostResources.host_threads minus one for the device-driving thread when
  * host_threads <= 0 was asked for, at most one per member) */
 int pbEnsemblePipelineHostThreads(void *pipeline);
+/* Sub-batches Run steps at the same time, each on its batch's own stream (1 ... 4, before Run; 2 with sub_batch -1, else
+ * 1; PB_PIPELINE_LANES overrides the automatic choice).  Rows and final states do not depend on it. */
+int pbEnsemblePipelineSetLanes(void *pipeline, int lanes);
 /* The size sub_batch -1 stands for: whole placement rounds of the producer pool (1 ... 8) that bring a sub-batch to
  * ~3 x 10^6 bots (smaller: every step carries a launch's ramp and drain; larger: the state leaves the Infinity Cache). */
 int pbEnsemblePipelineAutoSubBatch(unsigned bots_per_member, int producers);

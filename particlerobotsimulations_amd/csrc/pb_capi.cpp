@@ -829,6 +829,7 @@ struct Pipeline {
   bool haveCfg = false;
   std::vector<std::string> over;
   int nmembers = 0, sub = 0, threads = 1, ahead = 2;
+  int lanes = 1;  // sub-batches stepped at the same time (pbEnsemblePipelineRun)
   bool keepStates = false;
   std::vector<Member *> built;  // [nmembers], filled by the producers, taken by the consumer
   std::vector<char> ready;
@@ -1029,7 +1030,16 @@ void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *com
       botsPerMember = c0.params.nCells;
     }
   }
-  const int autoSub = pbEnsemblePipelineAutoSubBatch(botsPerMember, p->threads);
+  int autoSub = pbEnsemblePipelineAutoSubBatch(botsPerMember, p->threads);
+  // The automatic decomposition steps TWO sub-batches of half that size at the same time (a launch's ramp and drain
+  // overlap the other sub-batch's steady state, and together they still fit the Infinity Cache: configs[4] slice of
+  // 240 members, one pipeline of 30-member sub-batches 22.0 s, two lanes of 15 21.2 s, three of 10 21.1 s;
+  // tools/experiments/two_pipelines.py).  PB_PIPELINE_LANES overrides (1: one at a time, as an explicit sub_batch).
+  if (sub_batch == -1) {
+    p->lanes = 2;
+    if (const char *e = getenv("PB_PIPELINE_LANES")) p->lanes = std::max(1, std::min(4, atoi(e)));
+    if (p->lanes > 1) autoSub = std::max(1, autoSub / p->lanes);
+  }
   p->sub = sub_batch == -1 ? std::min(autoSub, nmembers) : (sub_batch < 1 || sub_batch > nmembers) ? nmembers : sub_batch;
   if (sub_batch == -1 && resume && checkpoint_dir && checkpoint_dir[0]) {
     // a sweep resumed with the automatic size continues with the size it was started with, whatever the number of
@@ -1094,15 +1104,32 @@ void pbEnsemblePipelineDestroy(void *pv) { delete (Pipeline *)pv; }
 
 int pbEnsemblePipelineHostThreads(void *pv) { return pv ? ((Pipeline *)pv)->threads : 0; }
 
+// Sub-batches stepped at the same time by Run (1 ... 4; before Run).  Rows and states do not depend on it.
+int pbEnsemblePipelineSetLanes(void *pv, int lanes) {
+  Pipeline *p = (Pipeline *)pv;
+  if (!p || p->consumedUpTo != 0 || lanes < 1 || lanes > 4) return -1;
+  p->lanes = lanes;
+  return 0;
+}
+
 long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, int *rows, pbEnsembleTimings *timings) {
   Pipeline *p = (Pipeline *)pv;
   if (!p || p->consumedUpTo != 0) return -1;  // one run per pipeline
   if (p->device >= 0 && pbSetDevice(p->device) != PB_OK) return -1;  // this thread may be new: batches go where Create was
   const double t0 = nowSeconds();
-  long steps = 0;
+  long steps = -1;
   int nrowsAll = 0;
-  for (int first = 0; first < p->nmembers; first += p->sub) {
+  const int nsub = (p->nmembers + p->sub - 1) / p->sub;
+  const int lanes = std::max(1, std::min(p->lanes, nsub));
+  std::mutex resMu;            // steps / nrowsAll / the timing sums
+  double waitS = 0.0, uploadS = 0.0, deviceS = 0.0;
+  // One sub-batch from "its members are placed" to "its rows are in `out`".  Runs on the calling thread, or -- with
+  // two lanes -- on two threads that take the sub-batches alternately, each on its batch's own stream: a launch's
+  // ramp and drain (~13 us of every step) then overlap the other sub-batch's steady state.
+  auto runSub = [&](int b) -> int {
+    const int first = b * p->sub;
     const int count = std::min(p->sub, p->nmembers - first);
+    double myWait = 0.0, myUpload = 0.0, myDevice = 0.0;
     Ensemble e;
     {
       const double w0 = nowSeconds();
@@ -1118,13 +1145,13 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
         e.members.push_back(p->built[k]);
         p->built[k] = nullptr;
       }
-      p->consumedUpTo = first + count;
-      p->tm.placement_wait_s += nowSeconds() - w0;
+      p->consumedUpTo = std::max(p->consumedUpTo, first + count);
+      myWait = nowSeconds() - w0;
     }
     p->cvRoom.notify_all();
     const double u0 = nowSeconds();
     float *const outSub = out ? out + (size_t)first * max_rows * 4 : nullptr;
-    p->nbots = e.members[0]->bot->getParams().nCells;
+    const unsigned nbHere = e.members[0]->bot->getParams().nCells;
     // restored from a checkpoint?  (all members of a sub-batch or none: they share one manifest)
     int nRestored = 0;
     for (Member *mk : e.members) nRestored += mk->saved ? 1 : 0;
@@ -1145,7 +1172,7 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
       if (nrows > max_rows) return -1;
       for (int k = 0; k < count && outSub; k++)
         memcpy(outSub + (size_t)k * max_rows * 4, e.members[k]->saved->rows.data(), sizeof(float) * 4 * (size_t)nrows);
-      p->tm.upload_s += nowSeconds() - u0;
+      myUpload = nowSeconds() - u0;
     } else {
       if (nRestored) {
         int gen = 0, r0 = 0, fin = 0;
@@ -1160,7 +1187,7 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
         return -1;
       }
       const double d0 = nowSeconds();
-      p->tm.upload_s += d0 - u0;
+      myUpload = d0 - u0;
       const long more = runSteps(&e, max_steps - e.stepsBefore, outSub, max_rows, &nrows);
       if (more < 0 || pbSimSynchronize(e.sim) != PB_OK) return -1;
       done = e.stepsBefore + more;
@@ -1174,11 +1201,11 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
           return -1;
         }
       }
-      p->tm.device_s += nowSeconds() - d0;
+      myDevice = nowSeconds() - d0;
     }
     if (p->keepStates && e.sim)
       for (int k = 0; k < count; k++) {
-        const size_t n = p->nbots;
+        const size_t n = nbHere;
         p->finalPos[first + k].resize(2 * n);
         p->finalVel[first + k].resize(2 * n);
         p->finalRad[first + k].resize(n);
@@ -1186,7 +1213,9 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
                             p->finalRad[first + k].data(), nullptr, nullptr, nullptr, nullptr) != PB_OK)
           return -1;
       }
-    if (first == 0) {
+    std::lock_guard<std::mutex> lock(resMu);
+    p->nbots = nbHere;
+    if (steps < 0) {
       steps = done;
       nrowsAll = nrows;
     } else if (done != steps || nrows != nrowsAll) {
@@ -1194,8 +1223,36 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
               nrows, steps, nrowsAll);
       return -1;
     }
+    waitS += myWait, uploadS += myUpload, deviceS += myDevice;
     p->tm.sub_batches++;
-  }  // (~Ensemble frees the sub-batch's device memory and its members)
+    return 0;
+  };  // (~Ensemble frees the sub-batch's device memory and its members)
+  if (lanes == 1) {
+    for (int b = 0; b < nsub; b++)
+      if (runSub(b) != 0) return -1;
+  } else {
+    std::atomic<int> next{0};
+    std::atomic<bool> bad{false};
+    auto lane = [&](bool setDevice) {
+      if (setDevice && p->device >= 0 && pbSetDevice(p->device) != PB_OK) bad = true;
+      for (int b; !bad && (b = next++) < nsub;)
+        if (runSub(b) != 0) {
+          bad = true;
+          std::lock_guard<std::mutex> lock(p->mu);  // (wake a lane that waits for members)
+          p->failed = true;
+          p->cvReady.notify_all();
+          p->cvRoom.notify_all();
+        }
+    };
+    std::vector<std::thread> extra;
+    for (int l = 1; l < lanes; l++) extra.emplace_back(lane, true);
+    lane(false);
+    for (std::thread &t : extra) t.join();
+    if (bad) return -1;
+  }
+  // (per lane: the lanes wait, upload and step at the same time)
+  p->tm.placement_wait_s = waitS / lanes, p->tm.upload_s = uploadS / lanes, p->tm.device_s = deviceS / lanes;
+  p->tm.lanes = lanes;
   p->tm.wall_s = nowSeconds() - t0;
   p->tm.placement_cpu_s = p->tm.placement_thread_wall_s = 0.0;
   for (double c : p->cpuSeconds) p->tm.placement_cpu_s += c;

@@ -442,13 +442,13 @@ int main(int argc, char **argv) {
     fprintf(jsonOut, "{\"cfg\": \"%s\", \"members\": %d, \"n_gpus\": %d, \"bots_per_member\": %d, \"steps_per_member\": %ld, "
            "\"rows_per_member\": %d, \"wall_s\": %.6f, \"sims_per_s\": %.6g, \"particle_steps_per_s\": %.6g, "
            "\"progress_toward_light_mean\": %.9g, \"progress_toward_light_std\": %.9g, "
-           "\"pipeline_rank0\": {\"sub_batch\": %d, \"sub_batches\": %d, \"host_threads\": %d, \"placement_cpu_s\": %.4f, "
+           "\"pipeline_rank0\": {\"sub_batch\": %d, \"sub_batches\": %d, \"lanes\": %d, \"host_threads\": %d, \"placement_cpu_s\": %.4f, "
            "\"placement_wait_s\": %.4f, \"upload_s\": %.4f, \"device_s\": %.4f, \"pinned_to_gpu_numa_node\": %s, "
            "\"numa_node\": %d, \"bound\": \"%s\"}, \"host\": \"%s\", \"resumed\": %s, "
            "\"collective\": \"ncclAllGather of %zu floats per rank (RCCL)\"}\n",
            cfgPath.c_str(), members, world, (int)hs[2], (long)hs[3], allRows, wall, members / wall,
            (double)members * hs[2] * hs[3] / wall, mean, sqrt(var > 0 ? var : 0), tm.sub_batch, tm.sub_batches,
-           tm.host_threads, tm.placement_cpu_s, tm.placement_wait_s, tm.upload_s, tm.device_s, tm.pinned ? "true" : "false",
+           tm.lanes, tm.host_threads, tm.placement_cpu_s, tm.placement_wait_s, tm.upload_s, tm.device_s, tm.pinned ? "true" : "false",
            tm.numa_node,
            // host-bound: this rank's placement CPU-seconds over its producer threads exceed the device's time
            tm.placement_cpu_s / (tm.host_threads > 0 ? tm.host_threads : 1) > tm.device_s + tm.upload_s ? "host" : "device",

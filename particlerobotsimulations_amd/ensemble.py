@@ -118,7 +118,7 @@ class Timings(C.Structure):
     _fields_ = [("wall_s", C.c_double), ("placement_cpu_s", C.c_double), ("placement_wait_s", C.c_double),
                 ("upload_s", C.c_double), ("device_s", C.c_double), ("sub_batches", C.c_int), ("sub_batch", C.c_int),
                 ("host_threads", C.c_int), ("pinned", C.c_int), ("numa_node", C.c_int),
-                ("placement_thread_wall_s", C.c_double)]
+                ("placement_thread_wall_s", C.c_double), ("lanes", C.c_int)]
 
 
 class HostResources(C.Structure):
@@ -173,7 +173,8 @@ class PipelinedEnsemble:
     rounds of the producer pool that bring a sub-batch to ~3e6 bots; for large members)."""
 
     def __init__(self, cfg_path, overrides_per_member, common=None, sub_batch=0, host_threads=0, max_rows=4096,
-                 keep_final_states=False, checkpoint_dir=None, resume=False):
+                 keep_final_states=False, checkpoint_dir=None, resume=False, lanes=None):
+        """lanes: sub-batches stepped at the same time (None: 2 with sub_batch -1, else 1)."""
         self._L = _pipeline_lib()
         self.m = len(overrides_per_member)
         self.max_rows = max_rows
@@ -191,6 +192,10 @@ class PipelinedEnsemble:
             1 if keep_final_states else 0, os.fsencode(checkpoint_dir) if checkpoint_dir else None, 1 if resume else 0)
         if not self._h:
             raise RuntimeError("pbEnsemblePipelineCreate failed")
+        if lanes is not None:
+            self._L.pbEnsemblePipelineSetLanes.argtypes = [C.c_void_p, C.c_int]
+            if self._L.pbEnsemblePipelineSetLanes(self._h, int(lanes)) != 0:
+                raise ValueError(f"lanes {lanes}")
 
     def run(self, max_steps=2 ** 62):
         """Every member up to max_steps timesteps (or to max_time); returns the timesteps per member."""

@@ -163,23 +163,28 @@ def test_pipelined_ensemble_stopped_and_resumed_equals_the_uninterrupted_run(tmp
 
 
 def test_automatic_sub_batch_resumes_with_the_size_it_started_with(tmp_path):
-    """sub_batch -1 = as many members as producer threads; a sweep started with 3 threads and resumed with 2 keeps the
-    3-member sub-batches of its checkpoint directory, and ends bit-identical to the uninterrupted run."""
+    """sub_batch -1 follows the number of producer threads (pbEnsemblePipelineAutoSubBatch: 12-member sub-batches for
+    3 threads and members this small, 8 for 2 threads); a sweep started with 3 threads and resumed with 2 keeps the
+    12-member sub-batches of its checkpoint directory, and ends bit-identical to the uninterrupted run -- which here
+    also steps its two sub-batches at the same time (lanes 2)."""
     from particlerobotsimulations_amd import ensemble
     cfg = EX("example.cfg")
-    members = [f"seed\n{3000 + k}" for k in range(7)]
+    members = [f"seed\n{3000 + k}" for k in range(20)]
     common = {"max_time": "18", "dump_interval": "6"}
     a = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=-1, host_threads=3)
     steps = a.run()
-    assert a.timings["sub_batch"] == 3 and a.timings["sub_batches"] == 3
+    assert a.timings["sub_batch"] == 12 and a.timings["sub_batches"] == 2 and a.timings["lanes"] == 2
     b = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=-1, host_threads=3, checkpoint_dir=str(tmp_path / "b"))
     assert b.run(700) == 700
     b.close()
     b2 = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=-1, host_threads=2, checkpoint_dir=str(tmp_path / "b"),
                                     resume=True)
-    assert b2.run() == steps and b2.timings["sub_batch"] == 3
+    assert b2.run() == steps and b2.timings["sub_batch"] == 12
     assert np.array_equal(b2.rows.view(np.uint32), a.rows.view(np.uint32))
     b2.close()
+    c = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=-1, host_threads=2)
+    assert c.run(10) == 10 and c.timings["sub_batch"] == 8      # (what 2 threads choose on their own)
+    c.close()
     a.close()
 
 

@@ -23,16 +23,26 @@ def test_rows_and_states_do_not_depend_on_the_split(orc, cfg, over):
     members = [f"seed\n{s}" for s in seeds]
     ref_rows, ref_steps, ref_states = ensemble.run_local(EX(cfg), members, common, final_state=True)
     assert ref_rows.shape[:2] == (16, 4) and ref_steps in (1260, 1261)
-    # even split, ragged split, one batch (two spellings), automatic (-1: one placement round = 3 members per sub-batch)
-    for sub, threads in ((8, 3), (5, 1), (32, 4), (0, 2), (-1, 3)):
+    # even split, ragged split, one batch (two spellings), automatic (-1: whole placement rounds that bring a
+    # sub-batch to ~3e6 bots, halved because two sub-batches are then stepped at the same time), and explicit splits
+    # stepped two and three sub-batches at a time
+    import ctypes as C
+    from particlerobotsimulations_amd import host
+    auto = host.lib().pbEnsemblePipelineAutoSubBatch
+    auto.argtypes, auto.restype = [C.c_uint, C.c_int], C.c_int
+    nbots = int(over.get("nCells", 500))
+    for sub, threads, lanes in ((8, 3, None), (5, 1, None), (32, 4, None), (0, 2, None), (-1, 3, None), (5, 2, 2),
+                                (3, 3, 3), (-1, 1, 1)):
         p = ensemble.PipelinedEnsemble(EX(cfg), members, common, sub_batch=sub, host_threads=threads,
-                                       keep_final_states=True)
+                                       keep_final_states=True, lanes=lanes)
         steps = p.run()
         tm = p.timings
         assert steps == ref_steps
-        used = threads if sub == -1 else sub
-        assert tm["sub_batches"] == (-(-16 // used) if 0 < used < 16 else 1) and tm["host_threads"] == threads
+        used = max(1, auto(nbots, threads) // 2) if sub == -1 else sub
+        nsub = -(-16 // used) if 0 < used < 16 else 1
+        assert tm["sub_batches"] == nsub and tm["host_threads"] == threads
         assert tm["sub_batch"] == (used if 0 < used < 16 else 16)
+        assert tm["lanes"] == min(lanes if lanes is not None else (2 if sub == -1 else 1), nsub)
         assert tm["wall_s"] > 0 and tm["device_s"] > 0 and tm["placement_cpu_s"] > 0
         rows, states = p.rows, p.final_states()
         p.close()
