@@ -101,6 +101,31 @@ def test_placement_in_a_rescaled_arena_matches_oracle(host, orc, min_radius, max
     assert_bit_equal(h.get("pos"), o.get("pos"), f"min_radius {min_radius}: placement")
 
 
+def test_random_parameter_draws_match_oracle(host, orc):
+    """Sizes x seeds x radii (incl. discs wider than the grid's cells, where nothing may be inferred from a disc's
+    neighbourhood) x payload runs, drawn at random with a fixed seed; tests/diag/placement_fuzz.py is the long form."""
+    rng = np.random.default_rng(4)
+    ran = 0
+    for _ in range(90):
+        rmin = float(np.round(10 ** rng.uniform(-1.7, 0.0), 4))
+        rmax = float(np.round(rmin * rng.choice([0.8, 1.0, 1.2, 1.5, 2.0, 3.0]), 4))
+        n = int(rng.choice([2, 3, 4, 7, 30, 200, 900, 2500]))
+        if 2.2 * rmin * np.sqrt(n) + 6 > min(0.45 * 512 * 2 * rmax, 60):
+            continue   # (the blob would leave the reference's 512-cell grid, which it indexes out of bounds)
+        payload = rng.random() < 0.25 and n > 3
+        kw = dict(nCells=n, seed=int(rng.integers(0, 2 ** 31 - 1)), min_radius=rmin, max_radius=rmax,
+                  nDead=-1 if payload else 0)
+        if payload:
+            kw["radFactor"] = float(rng.choice([1.0, 2.0, 5.0]))
+        path = os.path.join(ROOT, "examples", "example_object_transport.cfg" if payload else "example.cfg")
+        h = host.HostSim(path, engine="host", **{k: str(v) for k, v in kw.items()})
+        o = orc.Sim(orc.load_cfg(path, **kw), reset=True)
+        assert_bit_equal(h.get("pos"), o.get("pos"), f"{kw}")
+        o.close()
+        ran += 1
+    assert ran >= 50
+
+
 def test_large_placement_matches_oracle(host, orc):
     """10^4 bots (BASELINE config 2b's scale): the accept/reject loop stays in lock-step."""
     path = os.path.join(ROOT, "examples", "example_dead_cells.cfg")
