@@ -81,6 +81,20 @@ def test_automatic_sub_batch_is_whole_placement_rounds():
         assert ahead <= 3 * 8 * threads, (threads, ahead)
 
 
+def test_lanes_setter_validates_its_argument():
+    """pbEnsemblePipelineSetLanes: 1 ... 4 sub-batches stepped at a time (the stepping itself needs a GPU:
+    tests/test_gpu_ensemble_pipeline.py); anything else is refused, and the dry-run consumer is unaffected."""
+    from particlerobotsimulations_amd.ensemble import PipelinedEnsemble
+    for bad in (0, 5, -1):
+        with pytest.raises(ValueError):
+            PipelinedEnsemble(CFG, _members(4), {"nCells": "40"}, sub_batch=2, host_threads=2, lanes=bad)
+    ref, _ = _dry(0, 1)
+    p = PipelinedEnsemble(CFG, _members(len(ref)), {"nCells": "400"}, sub_batch=2, host_threads=2, lanes=3)
+    sums, _ = p.dry_run()
+    p.close()
+    assert np.array_equal(sums, ref)
+
+
 def test_bad_cfg_fails_cleanly():
     from particlerobotsimulations_amd.ensemble import PipelinedEnsemble
     p = PipelinedEnsemble(os.path.join(ROOT, "examples", "no_such.cfg"), _members(3), None, sub_batch=2, host_threads=2)
