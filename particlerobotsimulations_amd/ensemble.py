@@ -195,7 +195,8 @@ class PipelinedEnsemble:
         if lanes is not None:
             self._L.pbEnsemblePipelineSetLanes.argtypes = [C.c_void_p, C.c_int]
             if self._L.pbEnsemblePipelineSetLanes(self._h, int(lanes)) != 0:
-                raise ValueError(f"lanes {lanes}")
+                self.close()
+                raise ValueError(f"lanes {lanes}: 1 ... 4")
 
     def run(self, max_steps=2 ** 62):
         """Every member up to max_steps timesteps (or to max_time); returns the timesteps per member."""
