@@ -120,18 +120,18 @@ struct PlacementGrid {
       if (f(spill[o - 1].x, spill[o - 1].y, spill[o - 1].id)) return true;
     return false;
   }
-  // any listed bot within `limit` of (x,y) in the 3x3 cells around it?
-  // The decision is the reference's `length(...) < limit` with its three powf calls; a double
+  // any listed bot within `within` of (x,y) in the 3x3 cells around it?
+  // The decision is the reference's `length(...) < within` with its three powf calls; a double
   // precision squared distance settles every pair that is not within 1e-5 (relative) of the limit
   // -- hostLength is good to a few 1e-7 -- so the powf form only runs for pairs that (nearly) touch.
-  bool crowded(float x, float y, double limit) const {
+  bool crowded(float x, float y, double within) const {
     const int xc = col(x), yc = row(y);
-    const double far2 = limit * limit * (1.0 + 2e-5), near2 = limit * limit * (1.0 - 2e-5);
+    const double far2 = within * within * (1.0 + 2e-5), near2 = within * within * (1.0 - 2e-5);
     auto close = [&](float bx, float by, int) {
       const float dx = x - bx, dy = y - by;
       const double d2 = (double)dx * dx + (double)dy * dy;
       if (d2 > far2) return false;
-      return d2 < near2 || hostLength(dx, dy) < limit;
+      return d2 < near2 || hostLength(dx, dy) < within;
     };
     // (the candidate's own cell first: that is where a blocker most often is; the answer is an "any")
     if (anyIn(xc, yc, close)) return true;

@@ -194,8 +194,8 @@ void PbRunConfig::setParam(const std::string &name, const std::string &value) {
   else if (is("pb_force_variant", 16)) {
     // which force kernel the fused engine runs (include/particlebot_hip.h pbSimSetForceVariant): 0-2 exact, 3 the
     // opt-in tolerance kernel; anything else keeps the default
-    const long v = l();
-    force_variant = (v >= 0 && v <= 3) ? (int)v : -1;
+    const long variant = l();
+    force_variant = (variant >= 0 && variant <= 3) ? (int)variant : -1;
   }
   else if (is("pb_rng", 6)) {
     // phase-noise generator (include/particlebot_hip.h PB_RNG_*): "curand" = cuRAND-compatible XORWOW
