@@ -846,6 +846,10 @@ void Particlebot::placeRandom() {
   }
   const int tracked = grid.rings;  // (0: a grid finer than the discs, nothing is tracked)
   std::vector<unsigned char> buried(n, 0), fails(n, 0), retest(n, 4);
+  // PB_PLACEMENT_SELFCHECK=1: every draw decided by a mask is also tested the reference's way (tests/test_host_placement.py)
+  const char *const selfCheckEnv = getenv("PB_PLACEMENT_SELFCHECK");
+  const bool selfCheck = selfCheckEnv && selfCheckEnv[0] == '1';
+  unsigned long long checked = 0;
   for (uint i = 1; i < n; i++) {
     if (g_verbosePlacement) printf("Placing %d th disc\n", i);
     if (i == 2) {
@@ -876,6 +880,14 @@ void Particlebot::placeRandom() {
       if (level <= tracked ? grid.certainlyCrowded((int)anchor, level - 1, theta)
                           : (level <= 8 && (buried[anchor] >> (level - 1) & 1))) {
         // the draw of the angle is consumed, the outcome known
+        if (selfCheck) {
+          checked++;
+          if (!grid.crowded(hPos[2 * anchor] + 2 * r * cosf(theta), hPos[2 * anchor + 1] + 2 * r * sinf(theta), touch)) {
+            fprintf(stderr, "placeRandom self-check: disc %u, anchor %u, ring %d, theta %.9g is NOT crowded\n", i, anchor,
+                    level, (double)theta);
+            abort();
+          }
+        }
         rejections++;
         continue;
       }
@@ -915,6 +927,7 @@ void Particlebot::placeRandom() {
     hPos[2 * i + 1] = y;
     grid.addTracked((int)i, x, y);
   }
+  if (selfCheck) fprintf(stderr, "placeRandom self-check: %llu mask decisions verified\n", checked);
 }
 
 void Particlebot::placeFastBlob() {

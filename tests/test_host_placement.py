@@ -101,6 +101,24 @@ def test_placement_in_a_rescaled_arena_matches_oracle(host, orc, min_radius, max
     assert_bit_equal(h.get("pos"), o.get("pos"), f"min_radius {min_radius}: placement")
 
 
+def test_every_mask_decision_agrees_with_the_slow_test(host, capfd, monkeypatch):
+    """PB_PLACEMENT_SELFCHECK=1: every draw placeRandom rejects from a crowded-sector mask is also put through the
+    reference's own test (cosf, sinf, 3x3 scan, powf length) and the process aborts on the first disagreement:
+    millions of direct checks of "sufficient, never necessary", next to the blob-level comparisons above."""
+    monkeypatch.setenv("PB_PLACEMENT_SELFCHECK", "1")
+    total = 0
+    for cfg, kw in (("example_dead_cells.cfg", dict(nCells=45000, nDead=0, seed=3)),
+                    ("example_object_transport.cfg", dict(nCells=12001, seed=8)),
+                    ("example.cfg", dict(nCells=2500, min_radius=1.0, max_radius=1.5, seed=77)),
+                    ("example.cfg", dict(nCells=4000, min_radius=0.2, max_radius=0.3, seed=5))):
+        host.HostSim(os.path.join(ROOT, "examples", cfg), engine="host", **{k: str(v) for k, v in kw.items()})
+        err = capfd.readouterr().err
+        line = [x for x in err.splitlines() if "mask decisions verified" in x]
+        assert line and "NOT crowded" not in err, err[-300:]
+        total += int(line[-1].split(":")[1].split()[0])
+    assert total > 5_000_000
+
+
 def test_random_parameter_draws_match_oracle(host, orc):
     """Sizes x seeds x radii (incl. discs wider than the grid's cells, where nothing may be inferred from a disc's
     neighbourhood) x payload runs, drawn at random with a fixed seed; tests/diag/placement_fuzz.py is the long form."""
