@@ -89,6 +89,12 @@ int pbEnsemblePipelineHostThreads(void *pipeline);
 /* Sub-batches Run steps at the same time, each on its batch's own stream (1 ... 4, before Run; 2 with sub_batch -1, else
  * 1; PB_PIPELINE_LANES overrides the automatic choice).  Rows and final states do not depend on it. */
 int pbEnsemblePipelineSetLanes(void *pipeline, int lanes);
+/* Every member also writes dir/member_<id>.csv -- the file the reference writes for that member run on its own with
+ * testing 0 (particlebot.cpp:303-367: "Seed, s", the header, one row per dump interval), byte for byte: the centroid
+ * columns come from the reference's own fp32 sums over the bots in order (pbSimCentroidSums), not from the rows'
+ * accurately rounded mean.  ids[k]: the number of this pipeline's member k in the whole ensemble (NULL: k).  Before
+ * Run; refused together with checkpoints.  0, or -1. */
+int pbEnsemblePipelineSetCsvDir(void *pipeline, const char *dir, const int *ids);
 /* The size sub_batch -1 stands for: whole placement rounds of the producer pool (1 ... 8) that bring a sub-batch to
  * ~3 x 10^6 bots (smaller: every step carries a launch's ramp and drain; larger: the state leaves the Infinity Cache). */
 int pbEnsemblePipelineAutoSubBatch(unsigned bots_per_member, int producers);

@@ -195,6 +195,10 @@ int pbSimSetLayoutOf(pbSim *sim, unsigned member, const unsigned *orig, const un
 int pbSimSetForcesOf(pbSim *sim, unsigned member, const float *absForce_a, const float *absForce_r);
 /* centre of mass of every member: cxcy[2*k], cxcy[2*k+1]; reduced on the device in a fixed order */
 int pbSimCentroids(pbSim *sim, double *cxcy);
+/* The reference's own centroid SUMS of every simulation of the batch (sumxy[2k], sumxy[2k+1]): fp32, the bots added
+ * serially in original order as dumpParticlebot does (particlebot.cpp:335-338) -- bit for bit what its CSV's
+ * "Centroid X, Centroid Y" columns are divided from (pbSimCentroids above is the accurately rounded mean). */
+int pbSimCentroidSums(pbSim *sim, float *sumxy);
 
 /* Host arrays in ORIGINAL bot order; NULL pointers leave that array unchanged.
  * pos, vel: 2*n floats; rad, phase: n floats; dead: n ints. */

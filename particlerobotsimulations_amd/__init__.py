@@ -366,3 +366,10 @@ class Ensemble(Sim):
         out = np.empty((self.nsims, 2), np.float64)
         _capi.check(_capi.lib().pbSimCentroids(self._h, out.ctypes.data_as(C.POINTER(C.c_double))), "pbSimCentroids")
         return out
+
+    def centroid_sums(self):
+        """The reference's own fp32 centroid sums per member (bots added serially in order, particlebot.cpp:335-338):
+        what its CSV's centroid columns are divided from, bit for bit."""
+        out = np.empty((self.nsims, 2), np.float32)
+        _capi.check(_capi.lib().pbSimCentroidSums(self._h, out.ctypes.data_as(C.POINTER(C.c_float))), "pbSimCentroidSums")
+        return out

@@ -126,6 +126,7 @@ SYMBOLS = {
     "pbSimSetStateRangeOf": (_I, [_VP, _U, _U, _U, _VP, _VP, _VP, _VP, _VP]),
     "pbSimGetStateOf": (_I, [_VP, _U] + [_VP] * 7),
     "pbSimCentroids": (_I, [_VP, C.POINTER(C.c_double)]),
+    "pbSimCentroidSums": (_I, [_VP, C.POINTER(C.c_float)]),
     "pbSimGetLayoutOf": (_I, [_VP, _U, _VP, _VP, C.POINTER(_I)]),
     "pbSimSetLayoutOf": (_I, [_VP, _U, _VP, _VP]),
     "pbSimSetForcesOf": (_I, [_VP, _U, _VP, _VP]),

@@ -643,11 +643,33 @@ struct Ensemble {
   std::string ckptDir;
   int ckptSub = 0, ckptFirst = 0, ckptGen = 0;
   long stepsBefore = 0;
+  // per-member CSV files in the reference's own format (pbEnsemblePipelineSetCsvDir): directory, the members' numbers
+  // in the whole ensemble, the open files
+  std::string csvDir;
+  std::vector<int> csvIds;
+  std::vector<FILE *> csvFiles;
   ~Ensemble() {
+    for (FILE *f : csvFiles)
+      if (f) fclose(f);
     if (sim) pbSimDestroy(sim);
     for (auto *m : members) delete m;
   }
 };
+
+// One row of the reference's CSV with testing = 0 (particlebot.cpp:303-367: "Seed", the header and the time-0 row come
+// together), from the reference's own fp32 centroid sums -- the text particlebot_run writes for the member run alone.
+void writeCsvRow(FILE *fp, float time, unsigned seed, float sumX, float sumY, unsigned count, float light_x, float light_y) {
+  if (time == 0) {
+    fprintf(fp, "Seed, %u\n", seed);
+    fprintf(fp, "Time,");
+    fprintf(fp, "Centroid X, Centroid Y, Distance");
+    fprintf(fp, "\n");
+  }
+  fprintf(fp, "%f,", time);
+  fprintf(fp, "%f, %f, %f,", sumX / (float)count, sumY / (float)count,
+          powf(powf(sumX / (float)count - light_x, 2.0) + powf(sumY / (float)count - light_y, 2.0), 0.5));
+  fprintf(fp, "\n");
+}
 
 // device side: create the batched pbSim of already built members and upload their initial state
 bool uploadEnsemble(Ensemble *e) {
@@ -767,6 +789,24 @@ long runSteps(Ensemble *e, long max_steps, float *out, int max_rows, int *rows) 
         row[2] = (float)com[2 * k + 1];
         row[3] = (float)sqrt(dx * dx + dy * dy);
       }
+      if (!e->csvDir.empty()) {
+        std::vector<float> sums(2 * (size_t)m);
+        if (pbSimCentroidSums(e->sim, sums.data()) != PB_OK) return -1;
+        if (e->csvFiles.empty()) e->csvFiles.assign(m, nullptr);
+        for (int k = 0; k < m; k++) {
+          if (!e->csvFiles[k]) {
+            char name[64];
+            snprintf(name, sizeof name, "/member_%06d.csv", e->csvIds[k]);
+            e->csvFiles[k] = fopen((e->csvDir + name).c_str(), "w");
+            if (!e->csvFiles[k]) {
+              fprintf(stderr, "pbEnsemble: cannot write %s%s\n", e->csvDir.c_str(), name);
+              return -1;
+            }
+          }
+          const SimParams &p = e->members[k]->bot->getParams();
+          writeCsvRow(e->csvFiles[k], t, p.seed, sums[2 * k], sums[2 * k + 1], p.nCells, p.light_x, p.light_y);
+        }
+      }
       nrows++;
       e->haveRow = true;
       e->rowTime = t;
@@ -830,6 +870,8 @@ struct Pipeline {
   std::vector<std::string> over;
   int nmembers = 0, sub = 0, threads = 1, ahead = 2;
   int lanes = 1;  // sub-batches stepped at the same time (pbEnsemblePipelineRun)
+  std::string csvDir;       // pbEnsemblePipelineSetCsvDir
+  std::vector<int> csvIds;  // [nmembers]
   bool keepStates = false;
   std::vector<Member *> built;  // [nmembers], filled by the producers, taken by the consumer
   std::vector<char> ready;
@@ -1104,6 +1146,19 @@ void pbEnsemblePipelineDestroy(void *pv) { delete (Pipeline *)pv; }
 
 int pbEnsemblePipelineHostThreads(void *pv) { return pv ? ((Pipeline *)pv)->threads : 0; }
 
+// Every member also writes DIR/member_<id>.csv in the reference's own format (testing = 0: seed, header, one row per
+// dump interval with the reference's fp32 centroid), ids[k] = the number of this pipeline's member k in the whole
+// ensemble (NULL: k).  Before Run; not together with checkpoints (a resumed run could not rewrite the rows it skips).
+int pbEnsemblePipelineSetCsvDir(void *pv, const char *dir, const int *ids) {
+  Pipeline *p = (Pipeline *)pv;
+  if (!p || p->consumedUpTo != 0 || !dir || !dir[0] || !p->ckptDir.empty()) return -1;
+  (void)mkdir(dir, 0777);
+  p->csvDir = dir;
+  p->csvIds.resize(p->nmembers);
+  for (int k = 0; k < p->nmembers; k++) p->csvIds[k] = ids ? ids[k] : k;
+  return 0;
+}
+
 // Sub-batches stepped at the same time by Run (1 ... 4; before Run).  Rows and states do not depend on it.
 int pbEnsemblePipelineSetLanes(void *pv, int lanes) {
   Pipeline *p = (Pipeline *)pv;
@@ -1158,6 +1213,10 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
     if (nRestored != 0 && nRestored != count) {
       fprintf(stderr, "pbEnsemblePipelineRun: sub-batch %d is only partly in the checkpoint\n", first / p->sub);
       return -1;
+    }
+    if (!p->csvDir.empty()) {
+      e.csvDir = p->csvDir;
+      e.csvIds.assign(p->csvIds.begin() + first, p->csvIds.begin() + first + count);
     }
     e.ckptDir = p->ckptDir;
     e.ckptSub = first / p->sub;

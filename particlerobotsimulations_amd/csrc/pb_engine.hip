@@ -394,6 +394,23 @@ __global__ __launch_bounds__(64) void k_com_final(const double2 *__restrict__ pa
   if (threadIdx.x == 0) out[blockIdx.x] = make_double2(sx / (double)n, sy / (double)n);
 }
 
+// The reference's own centroid sums (particlebot.cpp:335-338: `sumX += hPos[i * 2]` over the bots in order, in fp32):
+// one lane per simulation adds its positions serially -- the order IS the value (at 10^5 bots the fp32 running sum is
+// good to ~5 digits, and the CSV prints 6) -- while the simulations of the batch run side by side.
+__global__ __launch_bounds__(64) void k_com_serial(const float2 *__restrict__ posOrig, uint32_t n, uint32_t nsims,
+                                                   float2 *__restrict__ out) {
+  const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+  if (k >= nsims) return;
+  const float2 *p = posOrig + (size_t)k * n;
+  float sx = 0.0f, sy = 0.0f;
+  for (uint32_t i = 0; i < n; i++) {
+    const float2 q = p[i];
+    sx += q.x;
+    sy += q.y;
+  }
+  out[k] = make_float2(sx, sy);
+}
+
 }  // namespace
 
 namespace {
@@ -1007,6 +1024,20 @@ int pbSimCentroids(pbSim *S, double *cxcy) {
     cxcy[2 * k] = S->hCom[k].x;
     cxcy[2 * k + 1] = S->hCom[k].y;
   }
+  return PB_OK;
+}
+
+int pbSimCentroidSums(pbSim *S, float *sumxy) {
+  if (!S || !sumxy) return PB_ERR_ARG;
+  useDevice(S);
+  const int c = S->cur;
+  float2 *const out = (float2 *)S->comOut;  // (8 of the 16 bytes per simulation the mean uses)
+  hipLaunchKernelGGL(k_com_scatter, gridOf(S), dim3(TILE), 0, S->stream, S->orig[c], S->pr[c], S->comPos, S->n);
+  hipLaunchKernelGGL(k_com_serial, dim3(cdiv(S->nsims, 64u)), dim3(64), 0, S->stream, S->comPos, S->n, S->nsims, out);
+  PB_TRY(hipGetLastError());
+  PB_TRY(hipMemcpyAsync(S->hCom, out, sizeof(float2) * S->nsims, hipMemcpyDeviceToHost, S->stream));
+  PB_TRY(hipStreamSynchronize(S->stream));
+  memcpy(sumxy, S->hCom, sizeof(float2) * S->nsims);
   return PB_OK;
 }
 

@@ -3,7 +3,7 @@
 // with one ncclAllGather over RCCL/xGMI (include/particlebot_ensemble.h).
 //
 //   particlebot_ensemble <config.cfg> --members M [--seed0 S] [--set NAME VALUE]...
-//                        [--sweep KEY V1 V2 ...] [--out FILE] [--sub-batch B] [--host-threads T]
+//                        [--sweep KEY V1 V2 ...] [--out FILE] [--csv-dir DIR] [--sub-batch B] [--host-threads T]
 //                        [--checkpoint DIR | --resume DIR] [--rendezvous FILE]
 //
 // Launch with any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (torchrun), OMPI_COMM_WORLD_* or
@@ -14,6 +14,8 @@
 // more), the host placing the next ones
 // while the device steps the current one.  --checkpoint DIR saves every member exactly at each summary row
 // (DIR/rank<r>/...); --resume DIR continues a killed sweep from there (same M, N and B), bit-identically.
+// --csv-dir DIR: member k also writes DIR/member_<k>.csv, byte for byte the CSV the reference writes for that member
+// run on its own with testing 0 (seed line, header, one row per dump interval with its fp32 centroid).
 //
 // Rendezvous: rank 0 creates the RCCL unique id and serves it over TCP on MASTER_ADDR:(MASTER_PORT + 17) -- not
 // MASTER_PORT itself, which a launcher's own store may hold; $PB_RENDEZVOUS_PORT overrides; default 127.0.0.1:29417 --
@@ -233,7 +235,7 @@ static bool fetchIdFile(const std::string &path, ncclUniqueId *id, double timeou
 }
 
 int main(int argc, char **argv) {
-  std::string cfgPath, outPath, rendezvous, ckptDir;
+  std::string cfgPath, outPath, rendezvous, ckptDir, csvDir;
   std::vector<std::pair<std::string, std::string>> sets;
   std::string sweepKey;
   std::vector<std::string> sweepVals;
@@ -244,6 +246,7 @@ int main(int argc, char **argv) {
     if (!strcmp(argv[i], "--members") && i + 1 < argc) members = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--seed0") && i + 1 < argc) seed0 = atol(argv[++i]);
     else if (!strcmp(argv[i], "--out") && i + 1 < argc) outPath = argv[++i];
+    else if (!strcmp(argv[i], "--csv-dir") && i + 1 < argc) csvDir = argv[++i];
     else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc) rendezvous = argv[++i];
     else if (!strcmp(argv[i], "--rendezvous-test")) rendezvousTest = true;
     else if (!strcmp(argv[i], "--sub-batch") && i + 1 < argc) subBatch = atoi(argv[++i]);
@@ -261,10 +264,14 @@ int main(int argc, char **argv) {
     } else if (argv[i][0] != '-' && cfgPath.empty()) cfgPath = argv[i];
     else {
       fprintf(stderr, "usage: %s <config.cfg> --members M [--seed0 S] [--set NAME VALUE]... [--sweep KEY V1 V2 ...] "
-                      "[--out FILE] [--sub-batch B] [--host-threads T] [--checkpoint DIR | --resume DIR] "
+                      "[--out FILE] [--csv-dir DIR] [--sub-batch B] [--host-threads T] [--checkpoint DIR | --resume DIR] "
                       "[--rendezvous FILE (single host)]\n", argv[0]);
       return 2;
     }
+  }
+  if (!csvDir.empty() && !ckptDir.empty()) {
+    fprintf(stderr, "particlebot_ensemble: --csv-dir cannot be combined with --checkpoint / --resume\n");
+    return 2;
   }
   if (!rendezvousTest && (cfgPath.empty() || members < 1)) {
     fprintf(stderr, "particlebot_ensemble: a configuration file and --members >= 1 are required\n");
@@ -379,6 +386,16 @@ int main(int argc, char **argv) {
     void *e = pbEnsemblePipelineCreateCheckpointed(cfgPath.c_str(), common.empty() ? nullptr : common.c_str(),
                                                    overPtr.data(), mine, subBatch, hostThreads, 0,
                                                    myCkpt.empty() ? nullptr : myCkpt.c_str(), resume ? 1 : 0);
+    if (e && !csvDir.empty()) {
+      // member k of the whole ensemble writes DIR/member_<k>.csv: the reference's own CSV of that member (testing 0)
+      std::vector<int> ids;
+      for (int k = rank; k < members; k += world) ids.push_back(k);
+      if (pbEnsemblePipelineSetCsvDir(e, csvDir.c_str(), ids.data()) != 0) {
+        fprintf(stderr, "rank %d: cannot write under %s\n", rank, csvDir.c_str());
+        pbEnsemblePipelineDestroy(e);
+        e = nullptr;
+      }
+    }
     if (!e) {
       fprintf(stderr, "rank %d: pbEnsemblePipelineCreate failed\n", rank);
       failed = 1;

@@ -173,8 +173,10 @@ class PipelinedEnsemble:
     rounds of the producer pool that bring a sub-batch to ~3e6 bots; for large members)."""
 
     def __init__(self, cfg_path, overrides_per_member, common=None, sub_batch=0, host_threads=0, max_rows=4096,
-                 keep_final_states=False, checkpoint_dir=None, resume=False, lanes=None):
-        """lanes: sub-batches stepped at the same time (None: 2 with sub_batch -1, else 1)."""
+                 keep_final_states=False, checkpoint_dir=None, resume=False, lanes=None, csv_dir=None, csv_ids=None):
+        """lanes: sub-batches stepped at the same time (None: 2 with sub_batch -1, else 1).
+        csv_dir: every member also writes csv_dir/member_<id>.csv, the file the reference writes for that member run
+        alone (testing 0), byte for byte; csv_ids: the members' numbers in the whole ensemble (default 0, 1, ...)."""
         self._L = _pipeline_lib()
         self.m = len(overrides_per_member)
         self.max_rows = max_rows
@@ -192,6 +194,12 @@ class PipelinedEnsemble:
             1 if keep_final_states else 0, os.fsencode(checkpoint_dir) if checkpoint_dir else None, 1 if resume else 0)
         if not self._h:
             raise RuntimeError("pbEnsemblePipelineCreate failed")
+        if csv_dir is not None:
+            ids = (C.c_int * self.m)(*[int(i) for i in csv_ids]) if csv_ids is not None else None
+            self._L.pbEnsemblePipelineSetCsvDir.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+            if self._L.pbEnsemblePipelineSetCsvDir(self._h, os.fsencode(csv_dir), ids) != 0:
+                self.close()
+                raise ValueError("csv_dir cannot be combined with checkpoints")
         if lanes is not None:
             self._L.pbEnsemblePipelineSetLanes.argtypes = [C.c_void_p, C.c_int]
             if self._L.pbEnsemblePipelineSetLanes(self._h, int(lanes)) != 0:

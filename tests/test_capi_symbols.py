@@ -108,7 +108,7 @@ def test_ensemble_header_symbols_are_exported_by_the_host_library():
                      "pbEnsembleSynchronize", "pbEnsembleGetState", "pbEnsembleNumBots", "pbEnsembleShard",
                      "pbEnsembleAssemble", "pbEnsemblePipelineCreate", "pbEnsemblePipelineCreateCheckpointed",
                      "pbEnsemblePipelineRun", "pbEnsemblePipelineDestroy", "pbEnsemblePipelineNumBots",
-                     "pbEnsemblePipelineGetState", "pbEnsemblePipelineDryRun", "pbEnsemblePipelineHostThreads", "pbEnsemblePipelineAutoSubBatch", "pbEnsemblePipelineSetLanes",
+                     "pbEnsemblePipelineGetState", "pbEnsemblePipelineDryRun", "pbEnsemblePipelineHostThreads", "pbEnsemblePipelineAutoSubBatch", "pbEnsemblePipelineSetLanes", "pbEnsemblePipelineSetCsvDir",
                      "pbHostGetResources", "pbHostParseCpuList"}
     L = host.lib()
     for n in names:

@@ -238,3 +238,42 @@ def test_payload_ensemble_with_xorwow_noise_resumes_exactly(tmp_path):
         for key in ("pos", "vel", "rad"):
             assert_bit_equal(sc[key], sa[key], f"member {k} {key}")
     a.close(), c.close()
+
+
+@pytest.mark.parametrize("cfg,extra", [("example_obstacle.cfg", ["--set", "max_time", "40"]),
+                                       ("example_object_transport.cfg", ["--set", "max_time", "30", "--set", "phase_std", "0.4"]),
+                                       ("example_dead_cells.cfg", ["--set", "max_time", "25", "--set", "nCells", "6000",
+                                                                   "--set", "nDead", "900"])])
+def test_ensemble_csv_dir_holds_the_reference_csv_of_every_member(tmp_path, cfg, extra, orc):
+    """--csv-dir: member k's file is, byte for byte, the CSV the reference writes for that member run on its own with
+    testing 0 (particlebot.cpp:303-367) -- its centroid columns are fp32 sums over the bots in order, which one lane per
+    member reproduces on the device (pbSimCentroidSums), not the rows' accurately rounded mean.  Checked against
+    particlebot_run (itself byte-identical to the oracle's dump: test_gpu_host.py) for three members, against the
+    oracle's own dump for one, and in a split that steps two sub-batches at a time."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29451")
+    common = ["--set", "dump_interval", "6", "--set", "testing", "0"] + extra
+    d = tmp_path / "csv"
+    r = run([ENS, EX(cfg), "--members", "7", "--seed0", "4100", "--sub-batch", "2", "--host-threads", "2", "--csv-dir", str(d)] + common,
+            env=dict(env, PB_PIPELINE_LANES="2"))
+    assert r.returncode == 0, r.stderr
+    assert sorted(os.listdir(d)) == [f"member_{k:06d}.csv" for k in range(7)]
+    for k in (0, 3, 6):
+        single = str(tmp_path / f"single_{k}.csv")
+        r = run([RUN, EX(cfg), "--quiet", "--set", "seed", str(4100 + k), "--set", "csv_filename", single] + common)
+        assert r.returncode == 0, r.stderr
+        a, b = open(single, "rb").read(), open(d / f"member_{k:06d}.csv", "rb").read()
+        assert a == b, (k, a[:200], b[:200])
+        assert a.startswith(f"Seed, {4100 + k}\nTime,Centroid X, Centroid Y, Distance\n".encode()) and a.count(b"\n") >= 6
+    # ... and the oracle's own dump of member 3
+    kv = {}
+    it = iter(common)
+    for flag in it:
+        name, value = next(it), next(it)
+        kv[name] = float(value) if "." in value else int(value)
+    from test_gpu_host import oracle_csv
+    path = str(tmp_path / "oracle_3.csv")
+    oracle_csv(orc, EX(cfg), path, seed=4103, **kv).close()
+    assert open(path, "rb").read() == open(d / "member_000003.csv", "rb").read()
+    # refused together with checkpoints
+    r = run([ENS, EX(cfg), "--members", "2", "--csv-dir", str(d), "--checkpoint", str(tmp_path / "ck")] + common, env=env)
+    assert r.returncode == 2 and "cannot be combined" in r.stderr
