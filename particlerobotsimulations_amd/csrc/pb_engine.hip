@@ -395,20 +395,40 @@ __global__ __launch_bounds__(64) void k_com_final(const double2 *__restrict__ pa
 }
 
 // The reference's own centroid sums (particlebot.cpp:335-338: `sumX += hPos[i * 2]` over the bots in order, in fp32):
-// one lane per simulation adds its positions serially -- the order IS the value (at 10^5 bots the fp32 running sum is
+// ONE lane per simulation adds its positions serially -- the order IS the value (at 10^5 bots the fp32 running sum is
 // good to ~5 digits, and the CSV prints 6) -- while the simulations of the batch run side by side.
-__global__ __launch_bounds__(64) void k_com_serial(const float2 *__restrict__ posOrig, uint32_t n, uint32_t nsims,
-                                                   float2 *__restrict__ out) {
-  const uint32_t k = blockIdx.x * 64u + threadIdx.x;
-  if (k >= nsims) return;
-  const float2 *p = posOrig + (size_t)k * n;
+__global__ __launch_bounds__(TILE) void k_com_serial(const float2 *__restrict__ posOrig, uint32_t n,
+                                                     float2 *__restrict__ out) {
+  // one workgroup per simulation: all lanes stage 2 048 positions at a time in LDS (coalesced), lane 0 adds them in
+  // order (a lone lane reading global memory spends ~70 cycles per bot waiting; out of LDS ~6)
+  constexpr uint32_t CH = 2048;
+  __shared__ float2 sh[CH];
+  const float2 *p = posOrig + (size_t)blockIdx.x * n;
   float sx = 0.0f, sy = 0.0f;
-  for (uint32_t i = 0; i < n; i++) {
-    const float2 q = p[i];
-    sx += q.x;
-    sy += q.y;
+  for (uint32_t c0 = 0; c0 < n; c0 += CH) {
+    const uint32_t cnt = n - c0 < CH ? n - c0 : CH;
+    for (uint32_t j = threadIdx.x; j < cnt; j += TILE) sh[j] = p[c0 + j];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t j = 0;
+      for (; j + 8u <= cnt; j += 8u) {
+        float2 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) q[u] = sh[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          sx += q[u].x;
+          sy += q[u].y;
+        }
+      }
+      for (; j < cnt; j++) {
+        sx += sh[j].x;
+        sy += sh[j].y;
+      }
+    }
+    __syncthreads();
   }
-  out[k] = make_float2(sx, sy);
+  if (threadIdx.x == 0) out[blockIdx.x] = make_float2(sx, sy);
 }
 
 }  // namespace
@@ -1033,7 +1053,7 @@ int pbSimCentroidSums(pbSim *S, float *sumxy) {
   const int c = S->cur;
   float2 *const out = (float2 *)S->comOut;  // (8 of the 16 bytes per simulation the mean uses)
   hipLaunchKernelGGL(k_com_scatter, gridOf(S), dim3(TILE), 0, S->stream, S->orig[c], S->pr[c], S->comPos, S->n);
-  hipLaunchKernelGGL(k_com_serial, dim3(cdiv(S->nsims, 64u)), dim3(64), 0, S->stream, S->comPos, S->n, S->nsims, out);
+  hipLaunchKernelGGL(k_com_serial, dim3(S->nsims), dim3(TILE), 0, S->stream, S->comPos, S->n, out);
   PB_TRY(hipGetLastError());
   PB_TRY(hipMemcpyAsync(S->hCom, out, sizeof(float2) * S->nsims, hipMemcpyDeviceToHost, S->stream));
   PB_TRY(hipStreamSynchronize(S->stream));
