@@ -713,7 +713,7 @@ def ensemble_end_to_end(workload, rank, world, dist, torch, members_per_gpu=None
         host_threads = max(1, (res["host_threads"] - 1) // len(batches))
     common_extra = dict(extra_common or {})
     pipes = [ensemble.PipelinedEnsemble(cfg, over, dict(common, **common_extra), sub_batch=full["sub_batch"],
-                                        host_threads=host_threads)
+                                        host_threads=host_threads, lanes=full.get("lanes"))
              for cfg, common, over, _ in batches]   # placement starts here, on the producer threads
     done = [0] * len(pipes)
     errors = [None] * len(pipes)
@@ -1051,6 +1051,9 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the ensemble end-to-end run")
     ap.add_argument("--sub-batch", type=int, default=None,
                     help="members per sub-batch of the end-to-end pipeline (default: FULL_RUN's value for the workload)")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="ensemble workloads, end to end: sub-batches stepped at the same time (default: 2 with the "
+                         "automatic sub-batch, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-survey-literal", action="store_true")
     ap.add_argument("--no-streamlined", action="store_true")
@@ -1089,6 +1092,8 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.sub_batch is not None and args.workload in FULL_RUN:
         FULL_RUN[args.workload]["sub_batch"] = args.sub_batch
+    if args.lanes is not None and args.workload in FULL_RUN:
+        FULL_RUN[args.workload]["lanes"] = args.lanes
     if args.members_per_gpu is None:
         args.members_per_gpu = 32 if args.workload == "ensemble4" else 8
 
