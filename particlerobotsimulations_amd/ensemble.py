@@ -323,6 +323,12 @@ def main():
     ap.add_argument("--set", nargs=2, action="append", default=[], metavar=("NAME", "VALUE"))
     ap.add_argument("--sweep", nargs="+", default=None, metavar="KEY V1 V2 ...")
     ap.add_argument("--out", default=None, help="write the gathered summaries (.npy) on rank 0")
+    ap.add_argument("--sub-batch", type=int, default=0,
+                    help="members per sub-batch of the placement/stepping pipeline (0: all at once; -1: automatic, for "
+                         "members of ~1e5 bots and more)")
+    ap.add_argument("--host-threads", type=int, default=0, help="producer threads (0: this rank's share of the host)")
+    ap.add_argument("--csv-dir", default=None,
+                    help="member k also writes DIR/member_<k>.csv: the reference's own CSV of that member (testing 0)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -338,10 +344,13 @@ def main():
     sweep = (args.sweep[0], args.sweep[1:]) if args.sweep else None
     ids = shard(args.members, rank, world)
     t0 = time.perf_counter()
-    e = LocalEnsemble(args.cfg, [member_overrides(k, args.seed0, sweep) for k in ids], dict(args.set))
-    placement_s = time.perf_counter() - t0  # host-side placement of this rank's members (all cores)
+    # (the same pipeline as bin/particlebot_ensemble: placement overlapped with stepping)
+    e = PipelinedEnsemble(args.cfg, [member_overrides(k, args.seed0, sweep) for k in ids], dict(args.set),
+                          sub_batch=args.sub_batch, host_threads=args.host_threads, csv_dir=args.csv_dir,
+                          csv_ids=ids if args.csv_dir else None)
     steps = e.run()
     rows = e.rows
+    placement_s = e.timings["placement_wait_s"] if e.timings else 0.0  # what the device waited for the host
     e.close()
     wall = time.perf_counter() - t0
     allrows = gather_summaries(rows, args.members, rank, world, dist, device)

@@ -277,3 +277,12 @@ def test_ensemble_csv_dir_holds_the_reference_csv_of_every_member(tmp_path, cfg,
     # refused together with checkpoints
     r = run([ENS, EX(cfg), "--members", "2", "--csv-dir", str(d), "--checkpoint", str(tmp_path / "ck")] + common, env=env)
     assert r.returncode == 2 and "cannot be combined" in r.stderr
+    # the Python front end (python -m particlerobotsimulations_amd.ensemble) drives the same pipeline
+    if cfg == "example_obstacle.cfg":
+        import sys
+        d2 = tmp_path / "csv_py"
+        r = run([sys.executable, "-m", "particlerobotsimulations_amd.ensemble", EX(cfg), "--members", "4", "--seed0", "4100",
+                 "--sub-batch", "3", "--csv-dir", str(d2)] + common, env=dict(env, PYTHONPATH=ROOT), cwd=ROOT)
+        assert r.returncode == 0, r.stderr
+        for k in range(4):
+            assert open(d2 / f"member_{k:06d}.csv", "rb").read() == open(d / f"member_{k:06d}.csv", "rb").read(), k
