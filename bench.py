@@ -234,6 +234,7 @@ def cpu_baseline(n_bots, pitch=LATTICE_PITCH, budget_s=12.0):
 
 ENSEMBLE_FORCE_VARIANT = None   # --workload ensemble4|5 --force-variant V: the members' pb_force_variant key
 HEADLINE_VARIANT = 2   # the exact kernel; --force-variant 3 (profiling the streamlined kernel) is flagged in the line
+HEADLINE_FORCE_SUMS = 0  # --force-sums 1: the arena itself keeps both magnitude sums (profiling that kernel; `headline: false`)
 
 
 def make_sim(pb, n, pitch, seed, lattice="square"):
@@ -241,6 +242,8 @@ def make_sim(pb, n, pitch, seed, lattice="square"):
     sp, keep = workload_params(n, seed=seed)
     sim = pb.Sim(sp, wall_half=240.0, keepalive=keep)
     sim.set_force_variant(HEADLINE_VARIANT)   # the exact kernel, whatever the environment says (legs that want 3 set it)
+    if HEADLINE_FORCE_SUMS:
+        sim.set_force_sums(1)
     sim.set_lanes_per_bot(0)
     sim.set_resident(0)
     pos = square_lattice(n, pitch) if lattice == "square" else hex_lattice(n, np.float32(pitch))
@@ -1070,6 +1073,10 @@ def main():
                     help="force kernel of the arena workload (default 2, the exact kernel = the headline).  3 = the "
                          "opt-in streamlined kernel: for profiling it with tools/profile.sh; the line then says "
                          "`headline: false`")
+    ap.add_argument("--force-sums", type=int, default=0, choices=[0, 1],
+                    help="1: the arena keeps BOTH magnitude sums (pbSimSetForceSums mode 1: everything collideD "
+                         "writes, impl.cuh:828-830) -- for profiling that kernel with tools/profile.sh; the line then "
+                         "says `headline: false`")
     ap.add_argument("--dry-run-device", action="store_true",
                     help="TEST ONLY (tests/test_bench_multirank.py): no GPU is touched -- gloo process group, the arena "
                          "replaced by a counter, ensemble members placed for real but never stepped; the line says "
@@ -1155,8 +1162,9 @@ def main():
             dist.destroy_process_group()
         return
 
-    global HEADLINE_VARIANT
+    global HEADLINE_VARIANT, HEADLINE_FORCE_SUMS
     HEADLINE_VARIANT = args.force_variant
+    HEADLINE_FORCE_SUMS = args.force_sums
     n = args.bots
     # host work for a later leg starts now, on its own thread, so that no device leg waits for it
     blob = BlobPlacement(n) if (rank == 0 and world == 1 and not args.no_blob) else None
@@ -1282,7 +1290,7 @@ def main():
                                  "IEEE square roots -- one fewer since Sum|F_attr| is only kept when something reads it --, DESIGN.md section 5): `valu` prices its instruction stream at the "
                                  "datasheet issue rate at the measured shader clock and at tools/valu_rate's rates; "
                                  "`traffic` (PMC) ~ algorithmic bytes, i.e. no wasted re-reads"},
-            "headline": args.force_variant == 2,
+            "headline": args.force_variant == 2 and not args.force_sums,
             "device_ms_timed_region": dev_ms,
             "device_prewarm": prewarm,
             "summaries_time_comx_comy": summaries,

@@ -96,7 +96,8 @@ int pbEnsemblePipelineSetLanes(void *pipeline, int lanes);
  * Run; refused together with checkpoints.  0, or -1. */
 int pbEnsemblePipelineSetCsvDir(void *pipeline, const char *dir, const int *ids);
 /* The size sub_batch -1 stands for: whole placement rounds of the producer pool (1 ... 8) that bring a sub-batch to
- * ~3 x 10^6 bots (smaller: every step carries a launch's ramp and drain; larger: the state leaves the Infinity Cache). */
+ * ~3 x 10^6 bots (smaller: every step carries a launch's ramp and drain; larger: the state leaves the Infinity Cache),
+ * never more than that many bots whatever the size of the pool. */
 int pbEnsemblePipelineAutoSubBatch(unsigned bots_per_member, int producers);
 unsigned pbEnsemblePipelineNumBots(void *pipeline);
 int pbEnsemblePipelineGetState(void *pipeline, int member, float *pos, float *vel, float *rad);
@@ -114,6 +115,8 @@ int pbEnsemblePipelineDryRun(void *pipeline, int dwell_ms, unsigned long long *c
  * (/sys/bus/pci/devices/<bus id>/numa_node >= 0) the producer threads are pinned to that node's cores
  * (local_cpulist, intersected with the affinity mask; PB_PIN_PRODUCERS=0 disables): members are placed in memory
  * next to the GPU that will receive them and the pools of different ranks do not migrate across sockets.
+ * A pinned pool always fits the node: with several ranks per node an automatic share larger than numa_cpus is
+ * clamped to it; a lone rank (or an explicit thread count) that is larger keeps its threads and is NOT pinned.
  * The reference has nothing of this (one device, one thread: main.cpp:350).
  * Test hooks: PB_CGROUP_ROOT (default /sys/fs/cgroup), PB_SYSFS_ROOT (default /sys), PB_PROC_SELF_CGROUP. */
 typedef struct pbHostResources {

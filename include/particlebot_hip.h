@@ -238,10 +238,13 @@ int pbSimSetResortEveryStep(pbSim *sim, int on);
  * provided the host libm has powf(x,2) == x*x for every float and a non-decreasing powf(., 0.5f), which
  * pbHostLibmCheck (libparticlebot_host.so; tests/test_libm_pin.py) verifies exhaustively.  1: the reference's own
  * loop on the host over all positions (8 n bytes per simulation): no assumption.  pbSetMinDistanceMode sets the
- * default of batches created afterwards (process-wide); the environment variable PB_MIN_DISTANCE_MODE (0 or 1) does the
- * same for a whole process tree (a batch's own pbSimSetMinDistanceMode still wins). */
+ * default of batches created afterwards (process-wide); the environment variable PB_MIN_DISTANCE_MODE (0 or 1) seeds
+ * that default for a whole process tree, read once at the first batch.  Precedence: a batch's own
+ * pbSimSetMinDistanceMode > pbSetMinDistanceMode > the environment > 0.  pbGetMinDistanceMode returns the default a
+ * batch created now would get. */
 int pbSimSetMinDistanceMode(pbSim *sim, int mode);
 int pbSetMinDistanceMode(int mode);
+int pbGetMinDistanceMode(void);
 
 /* The smallest non-negative float x with sqrtf(x) >= c (0 when c <= 0 or NaN): `length(v) < c` of the static-friction
  * hold (particlebot_impl.cuh:809-811) is decided as `dot(v,v) < pbHostSqrtThreshold(c)`, the same decision for every

@@ -110,6 +110,11 @@ def lib():
 
 BRACKET_VARIANTS = ("fma", "fma_powf")
 ORDER_VARIANT = "order"  # exact terms, the two-pass kernel's order of additions
+# the device powf sites of the obstacle / shadow tests (impl.cuh:214-229, 704-779): a power through base-2
+# logarithms; the correctly rounded result nudged by -1 / 0 / +1 ulp; FMA + __powf + device powf all at once
+DEVPOWF_VARIANTS = ("devpowf", "devpowf_ulp", "cuda_like")
+_VARIANT_TAGS = {"fma": b"fma", "fma_powf": b"fma+powf", "order": b"order", "devpowf": b"devpowf",
+                 "devpowf_ulp": b"devpowf_ulp", "cuda_like": b"fma+powf+devpowf"}
 
 
 def variant_lib(name):
@@ -119,7 +124,7 @@ def variant_lib(name):
     of the reference's arithmetic drifts from it (tests/test_fma_bracket.py)."""
     if name in (None, "exact"):
         return lib()
-    if name not in BRACKET_VARIANTS + (ORDER_VARIANT,):
+    if name not in _VARIANT_TAGS:
         raise ValueError(name)
     if name not in _variants:
         so = os.path.join(_HERE, f"libpb_oracle_{name}.so")
@@ -127,7 +132,7 @@ def variant_lib(name):
         if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < os.path.getmtime(src)):
             subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)], stdout=subprocess.DEVNULL)
         L = _bind(so)
-        want = {"fma": b"fma", "fma_powf": b"fma+powf", "order": b"order"}[name]
+        want = _VARIANT_TAGS[name]
         if L.orc_build_variant() != want:
             raise RuntimeError(f"{so} reports build variant {L.orc_build_variant()!r}, expected {want!r}")
         _variants[name] = L

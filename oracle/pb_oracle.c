@@ -42,9 +42,49 @@
 #define ORC_POW2(x) ((x) * (x))
 #endif
 
+/*
+ * The DEVICE powf sites (round 5).  Besides the two __powf calls the reference's kernels call the device
+ * library's powf(x, 2) and powf(x, 0.5f) in every obstacle and shadow test
+ * (particlebot_kernel_impl.cuh:214-216, 224, 226, 228-229 checkIntersectionCircle; :704-705, :719 circular
+ * obstacles; :757-779 rectangle corners).  CUDA's device powf is NOT correctly rounded (the CUDA C Programming
+ * Guide's accuracy table allows it several ulp over the full range), so the oracle's x*x / sqrtf at these sites
+ * is one member of a family, like its x*x at the __powf sites.  Two more bracket members:
+ *   -DORC_BRACKET_DEVPOWF=1  powf(x,2) -> exp2f(2*log2f(|x|)), powf(x,0.5f) -> exp2f(0.5f*log2f(x)): the textbook
+ *                            evaluation of a power through base-2 logarithms in fp32 (errors of a few ulp)
+ *   -DORC_BRACKET_DEVPOWF=2  the correctly rounded result moved by -1 / 0 / +1 ulp, chosen by a hash of the
+ *                            argument's bits (a quarter of the calls each way): what a faithfully-but-not-correctly
+ *                            rounded powf does, without committing to one implementation
+ * Only obstacle configurations (example_obstacle.cfg: circles; example_gap.cfg: rectangles; light_shadow) reach
+ * these sites.
+ */
+#if !defined(ORC_BRACKET_DEVPOWF)
+#define ORC_DPOW2(x) ((x) * (x))
+#define ORC_DSQRT(x) sqrtf(x)
+#elif ORC_BRACKET_DEVPOWF == 1
+#define ORC_DPOW2(x) exp2f(2.0f * log2f(fabsf(x)))
+#define ORC_DSQRT(x) exp2f(0.5f * log2f(x))
+#else
+static inline float orc_ulp_nudge(float exact, float arg) {
+  uint32_t b, k;
+  memcpy(&k, &arg, 4);
+  k = (k * 2654435761u) >> 30; /* 0: one ulp down, 1: one ulp up, 2, 3: as it is */
+  memcpy(&b, &exact, 4);
+  if (k > 1u || exact == 0.0f || (b & 0x7f800000u) == 0x7f800000u) return exact;
+  b = (k == 0u) ? b - 1u : b + 1u; /* (exact > 0 at every site) */
+  memcpy(&exact, &b, 4);
+  return exact;
+}
+#define ORC_DPOW2(x) orc_ulp_nudge((x) * (x), (x))
+#define ORC_DSQRT(x) orc_ulp_nudge(sqrtf(x), (x))
+#endif
+
 const char *orc_build_variant(void) {
 #if defined(ORC_BRACKET_ORDER)
   return "order";
+#elif defined(ORC_BRACKET_FMA) && defined(ORC_BRACKET_POWF) && defined(ORC_BRACKET_DEVPOWF)
+  return "fma+powf+devpowf";
+#elif defined(ORC_BRACKET_DEVPOWF)
+  return ORC_BRACKET_DEVPOWF == 1 ? "devpowf" : "devpowf_ulp";
 #elif defined(ORC_BRACKET_FMA) && defined(ORC_BRACKET_POWF)
   return "fma+powf";
 #elif defined(ORC_BRACKET_FMA)
@@ -469,21 +509,22 @@ static int intersects_segment(float x0, float y0, float x1, float y1, float x3, 
   return 1;
 }
 
-/* impl.cuh:211-236 checkIntersectionCircle (powf(x,2) -> x*x, powf(D,0.5f) -> sqrtf(D)) */
+/* impl.cuh:211-236 checkIntersectionCircle (powf(x,2) -> x*x, powf(D,0.5f) -> sqrtf(D); ORC_DPOW2 / ORC_DSQRT are
+ * exactly that in every build but the device-powf bracket members) */
 static int intersects_circle(float lx, float ly, float px, float py, float ox, float oy, float orad) {
-  float C1 = lx * lx + ly * ly;
-  float C2 = px * px + py * py;
-  float C3 = ox * ox + oy * oy;
+  float C1 = ORC_DPOW2(lx) + ORC_DPOW2(ly);
+  float C2 = ORC_DPOW2(px) + ORC_DPOW2(py);
+  float C3 = ORC_DPOW2(ox) + ORC_DPOW2(oy);
   float C4 = lx * px + ly * py;
   float C5 = lx * ox + ly * oy;
   float C6 = px * ox + py * oy;
   float A = C1 + C2 - 2 * C4;
   float B = -2 * C1 + 2 * C4 + 2 * C5 - 2 * C6;
-  float C = C1 + C3 - 2 * C5 - orad * orad;
-  float D = B * B - 4 * A * C;
+  float C = C1 + C3 - 2 * C5 - ORC_DPOW2(orad);
+  float D = ORC_DPOW2(B) - 4 * A * C;
   if (D >= 0) {
-    float R1 = (-B + sqrtf(D)) / 2 / A;
-    float R2 = (-B - sqrtf(D)) / 2 / A;
+    float R1 = (-B + ORC_DSQRT(D)) / 2 / A;
+    float R2 = (-B - ORC_DSQRT(D)) / 2 / A;
     if (R1 > 0 && R1 < 1) return 1;
     if (R2 > 0 && R2 < 1) return 1;
   }
@@ -705,14 +746,14 @@ void orc_collide(const OrcParams *P, float *newVel, float *absForce_a, float *ab
     for (int k = 0; k < P->n_cir_obstacles; k++) {
       const float ox = P->x_cir_obs[k], oy = P->y_cir_obs[k], orad = P->r_cir_obs[k];
       const float ddx = px - ox, ddy = py - oy;
-      const float dist_2 = ddx * ddx + ddy * ddy;
+      const float dist_2 = ORC_DPOW2(ddx) + ORC_DPOW2(ddy); /* :704 powf */
       const float reach = rad + orad;
-      if (dist_2 < reach * reach) {
+      if (dist_2 < ORC_DPOW2(reach)) { /* :705 powf */
         float dx = -px + ox, dy = -py + oy;
         const float l = len2(dx, dy);
         dx = dx / l;
         dy = dy / l;
-        const float ks = 2.0f * P->spring * (rad + orad - sqrtf(dist_2));
+        const float ks = 2.0f * P->spring * (rad + orad - ORC_DSQRT(dist_2)); /* :719 powf(dist_2, 0.5f) */
         obstacle_tail(P, vx, vy, dx, dy, ks * (-dx), ks * (-dy), &fx, &fy, &fr);
       }
     }
@@ -755,13 +796,13 @@ void orc_collide(const OrcParams *P, float *newVel, float *absForce_a, float *ab
           const float cys[4] = {y2, y2, y1, y1};
           for (int c = 0; c < 4; c++) {
             const float ex = px - cxs[c], ey = py - cys[c];
-            const float d2 = ex * ex + ey * ey;
-            if (d2 < rad * rad) {
+            const float d2 = ORC_DPOW2(ex) + ORC_DPOW2(ey); /* :757-779 powf */
+            if (d2 < ORC_DPOW2(rad)) {
               const float l = len2(ex, ey);
               dx = -ex / l;
               dy = -ey / l;
               hit = 1;
-              overlap = rad - sqrtf(d2);
+              overlap = rad - ORC_DSQRT(d2);
               break;
             }
           }

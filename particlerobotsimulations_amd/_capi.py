@@ -144,6 +144,7 @@ SYMBOLS = {
     "pbSimSetResortEveryStep": (_I, [_VP, _I]),
     "pbSimSetMinDistanceMode": (_I, [_VP, _I]),
     "pbSetMinDistanceMode": (_I, [_I]),
+    "pbGetMinDistanceMode": (_I, []),
     "pbHostSqrtThreshold": (C.c_float, [C.c_float]),
     "pbSimSetForceVariant": (_I, [_VP, _I]),
     "pbSimSetLanesPerBot": (_I, [_VP, _I]),

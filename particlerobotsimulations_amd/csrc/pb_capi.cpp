@@ -531,6 +531,22 @@ void describeResources(pbHostResources &r, int wanted) {
   r.numa_cpus = (int)cpus.size();
   const char *pin = getenv("PB_PIN_PRODUCERS");
   r.pin_producers = (r.numa_node >= 0 && r.numa_cpus > 0 && !(pin && pin[0] == '0')) ? 1 : 0;
+  // A pinned pool must FIT the node's cores: pinning 127 producers of a lone rank to the 64 (NPS4: 16) cores next to
+  // its GPU would oversubscribe them 2-8 x while the rest of the machine idles.  Several ranks per node: the cores
+  // beyond the node belong to the other ranks' pools, so the automatic share shrinks to the node; a lone rank, or an
+  // explicit thread count, keeps its threads and is not pinned.
+  const char *pinNote = r.pin_producers ? "pinned to the GPU's NUMA node" : "not pinned (no NUMA node reported for the device)";
+  if (pin && pin[0] == '0' && r.numa_node >= 0) pinNote = "not pinned (PB_PIN_PRODUCERS=0)";
+  if (r.pin_producers && r.host_threads > r.numa_cpus) {
+    const bool automatic = strcmp(why, "usable cores / ranks of the node") == 0;
+    if (automatic && r.local_world_size > 1) {
+      r.host_threads = r.numa_cpus;
+      pinNote = "pinned to the GPU's NUMA node, share clamped to its cores";
+    } else {
+      r.pin_producers = 0;
+      pinNote = "not pinned (the pool is larger than the GPU's NUMA node)";
+    }
+  }
   char quota[48];
   if (r.cgroup_cpus > 0.0) snprintf(quota, sizeof quota, "%.2f", r.cgroup_cpus);
   else snprintf(quota, sizeof quota, "none");
@@ -538,7 +554,7 @@ void describeResources(pbHostResources &r, int wanted) {
            "%d producer threads (%s): min(hardware %d, affinity %d, cgroup quota %s) = %d usable / %d rank(s) per node; "
            "%s",
            r.host_threads, why, r.hardware_threads, r.affinity_cpus, quota, r.usable_cpus, r.local_world_size,
-           r.pin_producers ? "pinned to the GPU's NUMA node" : "not pinned (no NUMA node reported for the device)");
+           pinNote);
 }
 
 // host threads for placement: this rank's share of the cores the process may really use
@@ -677,6 +693,20 @@ bool uploadEnsemble(Ensemble *e) {
   std::vector<SimParams> params;
   for (int k = 0; k < nmembers; k++) params.push_back(e->members[k]->bot->getParams());
   const PbRunConfig &c0 = *e->members[0]->cfg;
+  // the force kernel and the phase-noise generator are chosen per BATCH: a member that asks for another one than
+  // member 0 (a per-member override, `--sweep pb_force_variant 2 3`) would silently get member 0's -- refuse
+  for (int k = 1; k < nmembers; k++) {
+    const PbRunConfig &ck = *e->members[k]->cfg;
+    if (ck.force_variant != c0.force_variant || ck.rng_kind != c0.rng_kind) {
+      char msg[256];
+      snprintf(msg, sizeof msg,
+               "members of one batch must agree on pb_force_variant and pb_rng: member 0 has %d / %d, member %d has "
+               "%d / %d (run them as separate ensembles)",
+               c0.force_variant, c0.rng_kind, k, ck.force_variant, ck.rng_kind);
+      fprintf(stderr, "pbEnsemble: %s\n", msg);
+      return false;
+    }
+  }
   if (pbSimCreateBatch(&e->sim, params.data(), nmembers, c0.wallHalf()) != PB_OK) return false;
   if (c0.rng_kind != 0 && pbSimSetRng(e->sim, c0.rng_kind) != PB_OK) return false;
   if (c0.force_variant >= 0 && pbSimSetForceVariant(e->sim, c0.force_variant) != PB_OK) return false;  // pb_force_variant
@@ -778,7 +808,15 @@ long runSteps(Ensemble *e, long max_steps, float *out, int max_rows, int *rows) 
   for (;;) {
     // a row is due at time t; e->rowTime remembers the last one written so that a call which stopped
     // exactly at a dump time does not write it twice when the run is continued
-    if (out && !(t - di * floorf(t / di) > 0.01f) && nrows < max_rows && !(e->haveRow && e->rowTime == t)) {
+    const bool rowDue = !(t - di * floorf(t / di) > 0.01f) && !(e->haveRow && e->rowTime == t);
+    if (rowDue && !e->csvDir.empty() && (!out || nrows >= max_rows)) {
+      // the member CSVs are documented as byte for byte the reference's: never a silently shortened file
+      fprintf(stderr, "pbEnsemble: a CSV row is due at t = %g but the row buffer holds %d rows (max_rows %d): "
+              "%s/member_*.csv would stop here; raise max_rows or the dump interval\n",
+              (double)t, out ? nrows : 0, out ? max_rows : 0, e->csvDir.c_str());
+      return -1;
+    }
+    if (out && rowDue && nrows < max_rows) {
       if (pbSimCentroids(e->sim, com.data()) != PB_OK) return -1;
       for (int k = 0; k < m; k++) {
         const SimParams &p = e->members[k]->bot->getParams();
@@ -805,6 +843,10 @@ long runSteps(Ensemble *e, long max_steps, float *out, int max_rows, int *rows) 
           }
           const SimParams &p = e->members[k]->bot->getParams();
           writeCsvRow(e->csvFiles[k], t, p.seed, sums[2 * k], sums[2 * k + 1], p.nCells, p.light_x, p.light_y);
+          if (ferror(e->csvFiles[k])) {
+            fprintf(stderr, "pbEnsemble: write error on %s/member_%06d.csv\n", e->csvDir.c_str(), e->csvIds[k]);
+            return -1;
+          }
         }
       }
       nrows++;
@@ -816,7 +858,19 @@ long runSteps(Ensemble *e, long max_steps, float *out, int max_rows, int *rows) 
         return -1;
       }
     }
-    if (t > c0.params.max_time || steps >= max_steps) break;
+    if (t > c0.params.max_time) {
+      // the run is over: the member CSVs are complete only if every buffered byte reached the disk
+      for (size_t k = 0; k < e->csvFiles.size(); k++) {
+        FILE *f = e->csvFiles[k];
+        e->csvFiles[k] = nullptr;
+        if (f && fclose(f) != 0) {
+          fprintf(stderr, "pbEnsemble: cannot finish %s/member_%06d.csv\n", e->csvDir.c_str(), e->csvIds[k]);
+          return -1;
+        }
+      }
+      break;
+    }
+    if (steps >= max_steps) break;
     // host events at this step: dead-bot draws (those due at time 0 came with the placement)
     for (int k = 0; k < m; k++) {
       Member *mk = e->members[k];
@@ -1037,7 +1091,11 @@ int pbEnsemblePipelineAutoSubBatch(unsigned bots_per_member, int producers) {
   const int threads = std::max(producers, 1);
   const double want = 3.0e6 / (double)std::max(bots_per_member, 1u);
   const int rounds = std::max(1, std::min(8, (int)(want / threads + 0.5)));
-  return threads * rounds;
+  // ... but never more bots than the cache target, however many producers the host has (127 producers x 10^5 bots
+  // would be 12.7 x 10^6 bots in flight over the two lanes, 4 x the target; with 10^6-bot members (ahead + 1 + lanes)
+  // sub-batches of placed members are alive on the host): a pool larger than the sub-batch simply works further ahead
+  const int cap = std::max(1, (int)(want + 0.5));
+  return std::min(threads * rounds, std::max(cap, 1));
 }
 
 void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *common_overrides,

@@ -463,8 +463,20 @@ int resort(pbSim *S) {
   return PB_OK;
 }
 
-// process-wide default of pbSimSetMinDistanceMode for batches created from now on (pbSetMinDistanceMode)
-int g_minDistanceMode = 0;
+// process-wide default of pbSimSetMinDistanceMode for batches created from now on (pbSetMinDistanceMode).  -1: not
+// decided yet -- the first use seeds it from PB_MIN_DISTANCE_MODE (0 or 1; anything else: 0), a default that CHILD
+// processes inherit (tests/conftest.py exports it when this host's libm fails the check, so that the binaries the
+// tests spawn take the reference's host loop too).  An explicit pbSetMinDistanceMode always wins over the environment.
+int g_minDistanceMode = -1;
+static int minDistanceDefault() {
+  if (g_minDistanceMode < 0) {
+    int m = 0;
+    if (const char *v = getenv("PB_MIN_DISTANCE_MODE"))
+      if ((v[0] == '0' || v[0] == '1') && v[1] == 0) m = v[0] - '0';
+    g_minDistanceMode = m;
+  }
+  return g_minDistanceMode;
+}
 
 int phaseUpdate(pbSim *S) {
   // particlebot.cpp:212-237.  The reference copies every position to the host and takes
@@ -696,11 +708,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   }
   pbSim *S = new pbSim();
   (void)hipGetDevice(&S->device);
-  S->minDistanceMode = g_minDistanceMode;
-  // a process-wide default that CHILD processes inherit (tests/conftest.py exports it when this host's libm fails the
-  // check, so that the binaries the tests spawn take the reference's host loop too); 0 and 1 only, no other effect
-  if (const char *v = getenv("PB_MIN_DISTANCE_MODE"))
-    if ((v[0] == '0' || v[0] == '1') && v[1] == 0) S->minDistanceMode = v[0] - '0';
+  S->minDistanceMode = minDistanceDefault();
   S->host = params[0];
   S->host.x1obs = S->host.x2obs = S->host.y1obs = S->host.y2obs = nullptr;
   S->host.x_cir_obs = S->host.y_cir_obs = S->host.r_cir_obs = nullptr;
@@ -1150,6 +1158,8 @@ int pbSetMinDistanceMode(int mode) {
   g_minDistanceMode = mode;
   return PB_OK;
 }
+
+int pbGetMinDistanceMode(void) { return minDistanceDefault(); }
 
 float pbHostSqrtThreshold(float c) { return pbSqrtThreshold(c); }
 

@@ -75,6 +75,16 @@ CASES = {
                                                 light_x=-40.0, light_y=0.0), EPOCHS_SHORT,
                                "configs[4]: one sweep member, 10^5 bots, 20 % dead, light at (-40, 0)"),
 }
+# Round 5: the cases that reach the DEVICE powf sites (obstacle and shadow tests, impl.cuh:214-229, 704-779).
+CASES.update({
+    "cfg_gap_1000": (lambda orc: _cfg(orc, "example_gap.cfg"), EPOCHS_FULL,
+                     "examples/example_gap.cfg verbatim (1000 bots, two rectangular obstacles: faces and corners)"),
+    "cfg4_obstacle_500_shadow": (lambda orc: _cfg(orc, "example_obstacle.cfg", seed=1000, light_shadow=1), EPOCHS_FULL,
+                                 "configs[3]'s obstacle course with light_shadow 1: every phase update runs "
+                                 "checkIntersectionCircle for every bot (epoch 1195 crosses one)"),
+})
+# cases whose obstacles the device-powf bracket members (orclib.DEVPOWF_VARIANTS) can act on
+DEVPOWF_CASES = ("cfg4_obstacle_500", "cfg_gap_1000", "cfg4_obstacle_500_shadow")
 CHEAP_CASES = ("cfg1_example_300", "cfg2a_dead_cells_100", "cfg4_obstacle_500", "cfg4_object_transport_201")
 
 

@@ -24,14 +24,17 @@ import fma_bracket as fb  # noqa: E402
 
 
 def main():
-    def factory(P):
-        return [fb.OracleCandidate(orc, P, v) for v in orc.BRACKET_VARIANTS + (orc.ORDER_VARIANT,)]
+    def factory_for(name):
+        variants = orc.BRACKET_VARIANTS + (orc.ORDER_VARIANT,)
+        if name in fb.DEVPOWF_CASES:  # the device-powf members only differ where there are obstacles
+            variants += orc.DEVPOWF_VARIANTS
+        return lambda P: [fb.OracleCandidate(orc, P, v) for v in variants]
 
     names = sys.argv[1:] or list(fb.CASES)
     results = {}
     for name in names:
         t = time.time()
-        results[name] = fb.measure_case(orc, name, factory)
+        results[name] = fb.measure_case(orc, name, factory_for(name))
         for line in fb.format_rows(results[name]):
             print(line)
         print(f"  ({time.time() - t:.1f} s)", flush=True)
@@ -44,7 +47,13 @@ def main():
         "candidates": {"fma": "oracle/libpb_oracle_fma.so: kernel functions with fp-contract=fast + FMA",
                        "fma_powf": "oracle/libpb_oracle_fma_powf.so: that + exp2f(2*log2f(x)) at impl.cuh:586,589",
                        "order": "oracle/libpb_oracle_order.so: the oracle's own terms, a bot's contact terms added after its "
-                                "last candidate (the order of additions of the product's two-pass tolerance kernel)"},
+                                "last candidate (the order of additions of the product's two-pass tolerance kernel)",
+                       "devpowf": "oracle/libpb_oracle_devpowf.so (obstacle cases only): the device powf sites of the "
+                                  "obstacle and shadow tests (impl.cuh:214-229, 704-705, 719, 757-779) as "
+                                  "exp2f(y*log2f(x)); nothing else changed",
+                       "devpowf_ulp": "oracle/libpb_oracle_devpowf_ulp.so: the same sites, the correctly rounded result "
+                                      "moved by -1 / 0 / +1 ulp by a hash of the argument",
+                       "cuda_like": "oracle/libpb_oracle_cuda_like.so: fma + the __powf model + the device-powf model"},
         "summary": {n: fb.summarise(r) for n, r in results.items()},
         "cases": results,
     }

@@ -148,3 +148,32 @@ def test_force_forms_table_is_enumerable_without_a_gpu(capi):
     f = capi.pbForceForm()
     assert L.pbForceFormGet(n, C.byref(f)) == 2 and L.pbForceFormGet(-1, C.byref(f)) == 2
     assert L.pbSimSelectForceForm(None, 0) == 2
+
+
+def test_min_distance_mode_precedence_api_over_environment(capi):
+    """PB_MIN_DISTANCE_MODE used to be applied AFTER the process-wide default in pbSimCreateBatch, so an
+    inherited PB_MIN_DISTANCE_MODE=0 silently overrode an explicit pbSetMinDistanceMode(1) (chosen because this
+    host's libm failed pbHostLibmCheck).  The environment now only seeds the default; the API call wins.  Each case
+    in a child process (the default is decided once per process)."""
+    import subprocess
+    import sys
+    child = ("import sys; sys.path.insert(0, %r)\n"
+             "from particlerobotsimulations_amd import _capi\n"
+             "L = _capi.lib()\n"
+             "a = L.pbGetMinDistanceMode()\n"
+             "if len(sys.argv) > 1: assert L.pbSetMinDistanceMode(int(sys.argv[1])) == 0\n"
+             "print(a, L.pbGetMinDistanceMode())\n") % ROOT
+
+    def run(env_value, *args):
+        env = {k: v for k, v in os.environ.items() if k != "PB_MIN_DISTANCE_MODE"}
+        if env_value is not None:
+            env["PB_MIN_DISTANCE_MODE"] = env_value
+        out = subprocess.check_output([sys.executable, "-c", child, *args], env=env, text=True)
+        return [int(x) for x in out.split()[-2:]]
+
+    assert run(None) == [0, 0]
+    assert run("1") == [1, 1]
+    assert run("0", "1") == [0, 1]      # the case that used to lose
+    assert run("1", "0") == [1, 0]
+    assert run("7") == [0, 0] and run("11") == [0, 0]
+    assert capi.lib().pbSetMinDistanceMode(2) != 0

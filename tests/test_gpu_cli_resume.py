@@ -286,3 +286,29 @@ def test_ensemble_csv_dir_holds_the_reference_csv_of_every_member(tmp_path, cfg,
         assert r.returncode == 0, r.stderr
         for k in range(4):
             assert open(d2 / f"member_{k:06d}.csv", "rb").read() == open(d / f"member_{k:06d}.csv", "rb").read(), k
+
+
+def test_csv_dir_never_writes_a_silently_shortened_file(tmp_path, capfd):
+    """the member CSVs were written inside the `out && nrows < max_rows` branch, so a run with more dump
+    rows than max_rows (4096 in the runner) stopped its files there and still returned success.  Now the run fails
+    with a message when a row is due that the buffer cannot hold; with room it succeeds and the files are closed
+    (checked) at the end of the run."""
+    from particlerobotsimulations_amd import ensemble
+    members = [f"seed\n{5200 + k}" for k in range(3)]
+    common = {"max_time": "30", "dump_interval": "6", "testing": "0"}
+    d = tmp_path / "short"
+    d.mkdir()
+    p = ensemble.PipelinedEnsemble(EX("example.cfg"), members, common, sub_batch=0, host_threads=2, max_rows=3,
+                                   csv_dir=str(d))
+    with pytest.raises(RuntimeError):
+        p.run()
+    p.close()
+    assert "a CSV row is due" in capfd.readouterr().err
+    d2 = tmp_path / "whole"
+    d2.mkdir()
+    p = ensemble.PipelinedEnsemble(EX("example.cfg"), members, common, sub_batch=0, host_threads=2, max_rows=16,
+                                   csv_dir=str(d2))
+    assert p.run() > 0
+    text = open(d2 / "member_000001.csv").read()      # complete BEFORE close(): the run closed it
+    p.close()
+    assert text.startswith("Seed, 5201\n") and text.count("\n") == 2 + 6   # seed, header, rows at 0, 6, ... 30

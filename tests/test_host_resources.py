@@ -120,12 +120,45 @@ def test_numa_node_of_the_gpu_from_sysfs(tmp_path):
     dev = sysroot / "bus" / "pci" / "devices" / "0000:c1:00.0"
     dev.mkdir(parents=True)
     (dev / "numa_node").write_text("1\n")
-    (dev / "local_cpulist").write_text(f"{mine[0]}-{mine[min(1, len(mine) - 1)]}\n")
+    (dev / "local_cpulist").write_text(f"{mine[0]}-{mine[-1]}\n")   # (a node the pool fits in; smaller: next test)
     env = {"PB_SYSFS_ROOT": str(sysroot), "PB_FAKE_PCI_BUS_ID": "0000:C1:00.0"}
     r = run_child(env)["res"]
-    assert r["numa_node"] == 1 and r["numa_cpus"] == min(2, len(mine)) and r["pin_producers"] == 1
+    assert r["numa_node"] == 1 and r["numa_cpus"] == len(mine) and r["pin_producers"] == 1
     assert r["pci_bus_id"] == "0000:c1:00.0" and "pinned to the GPU's NUMA node" in r["rule"]
     assert run_child(dict(env, PB_PIN_PRODUCERS="0"))["res"]["pin_producers"] == 0
     (dev / "numa_node").write_text("-1\n")
     r = run_child(env)["res"]
     assert r["numa_node"] == -1 and r["pin_producers"] == 0 and "not pinned" in r["rule"]
+
+
+def test_a_pinned_pool_never_exceeds_the_numa_node(tmp_path):
+    """producers were pinned to the GPU's NUMA node but the pool was still sized from the whole machine (a
+    lone rank on a two-socket host: 127 threads on 64 cores).  Now a lone rank whose share is larger than the node is
+    not pinned; with several ranks per node the automatic share is clamped to the node's cores; an explicit thread
+    count is honoured unpinned.  The pipeline's pool follows."""
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) < 4:
+        pytest.skip("needs four usable CPUs")
+    sysroot = tmp_path / "sys"
+    dev = sysroot / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("0\n")
+    (dev / "local_cpulist").write_text(f"{mine[0]}-{mine[1]}\n")   # a two-core node
+    env = {"PB_SYSFS_ROOT": str(sysroot), "PB_FAKE_PCI_BUS_ID": "0000:c1:00.0"}
+    env.update(fake_cgroup(tmp_path, "max 100000\n"))
+    lone = run_child(env, "pipeline")
+    r = lone["res"]
+    assert r["numa_cpus"] == 2 and r["host_threads"] == min(len(mine), r["hardware_threads"]) > 2
+    assert r["pin_producers"] == 0 and "larger than the GPU's NUMA node" in r["rule"]
+    assert lone["producers"] == r["host_threads"] - 1
+    shared = run_child(dict(env, LOCAL_WORLD_SIZE="2"), "pipeline")
+    r = shared["res"]
+    assert r["pin_producers"] == 1 and r["host_threads"] == 2 and "clamped" in r["rule"]
+    assert shared["producers"] <= r["numa_cpus"]
+    assert shared["checksums"] == lone["checksums"]
+    r = run_child(dict(env, LOCAL_WORLD_SIZE="2", PB_HOST_THREADS="3"))["res"]
+    assert r["host_threads"] == 3 and r["pin_producers"] == 0
+    # a pool that fits is pinned as before
+    (dev / "local_cpulist").write_text(f"{mine[0]}-{mine[-1]}\n")
+    r = run_child(env)["res"]
+    assert r["pin_producers"] == 1 and r["host_threads"] <= r["numa_cpus"]

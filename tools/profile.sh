@@ -7,6 +7,7 @@ TAG=${1:-run}; shift || true
 ARGS=${@:---force-variant ${PB_PROFILE_VARIANT:-2} --steps 400 --warmup 100 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg --no-both-sums --no-host-round-trip}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+export PB_PROFILE_ARGS="$ARGS"   # summarize_profile.py quotes the command in traffic.json
 export TMPDIR=/tmp
 run() { # name, rocprof flags...
   local name=$1; shift

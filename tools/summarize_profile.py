@@ -105,7 +105,10 @@ def valu_roofline(root, d, avg_ns_profiled, simds=1024):
     ns_trans = (r["rcp"] + r["sqrt"] + r["rsq"]) / 3.0
     valu, trans = d["SQ_INSTS_VALU"], d["SQ_INSTS_VALU_TRANS_F32"]
     valu_ns = ((valu - trans) * ns_simple + trans * ns_trans) / simds
-    launch_us = bench["roofline"]["avg_launch_us"]
+    launch_us = bench.get("roofline", {}).get("avg_launch_us")
+    if launch_us is None:
+        # ensemble workloads: the line has no per-launch figure; price against the PROFILED launch time
+        launch_us = avg_ns_profiled / 1e3
     mhz = rates.get("in_kernel_mhz")
     return {"valu_roofline_frac": valu_ns / 1e3 / launch_us, "valu_time_us": valu_ns / 1e3,
             "valu_rate_mhz": (sum(mhz.values()) / len(mhz)) if mhz else None,
@@ -117,6 +120,8 @@ def valu_roofline(root, d, avg_ns_profiled, simds=1024):
 def main():
     root = sys.argv[1]
     traffic_json = sys.argv[2] if len(sys.argv) > 2 else None
+    # the kernel whose counters go into traffic_json: first kernel (by total time) whose name contains this
+    traffic_kernel = os.environ.get("PB_TRAFFIC_KERNEL", "k_force")
     agg, meta = kernel_trace(root)
     total = sum(sum(v) for v in agg.values()) or 1
     print(f"# rocprofv3 summary: {os.path.basename(root)}\n")
@@ -187,7 +192,7 @@ def main():
             write = d.get("WRITE_SIZE", 0.0) * 1024
             # (the dominant k_force form: the kernels are visited by descending total time; since round 3 the
             #  fused and the un-fused launch are the same kernel, `fuse` being a runtime flag)
-            if traffic_json and k.startswith("k_force") and not getattr(main, "_wrote_traffic", False):
+            if traffic_json and traffic_kernel in k and not getattr(main, "_wrote_traffic", False):
                 main._wrote_traffic = True
                 import json
                 valu = {}
@@ -206,8 +211,8 @@ def main():
                                "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                                "avg_launch_us_profiled": avg_ns / 1e3,
                                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
-                                         "`python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline "
-                                         "--no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg`; FETCH_SIZE x2 (gfx950 wide-read correction) "
+                                         "`python3 bench.py " + os.environ.get("PB_PROFILE_ARGS", "--steps 400 --warmup 100 --no-cpu-baseline "
+                                         "--no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg") + "`; FETCH_SIZE x2 (gfx950 wide-read correction) "
                                          "x1024, WRITE_SIZE x1024 (MI355X_MICROARCH.md, HBM section)"}, fh)
             print(f"- derived: HBM-side traffic per launch = read {fetch/1e6:.1f} MB (FETCH_SIZE x2 x1024) + "
                   f"write {write/1e6:.1f} MB = {(fetch+write)/1e6:.1f} MB; at {avg_ns/1e3:.1f} us/launch = "
