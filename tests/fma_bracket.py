@@ -39,6 +39,7 @@ SYNC_KEYS = ("pos", "vel", "rad", "phase", "dead", "absForce_a", "absForce_r", "
 
 EPOCHS_FULL = (50, 200, 400, 1195, 1400, 3000)  # 1195: the window crosses the phase update at step 1200
 EPOCHS_SHORT = (50, 400, 1195)
+EPOCHS_RIM = (0, 110, 400, 1195, 1400, 3000)   # 0: the placed blob's first ten steps against the moved obstacles
 
 
 def _cfg(orc, name, **over):
@@ -75,8 +76,52 @@ CASES = {
                                                 light_x=-40.0, light_y=0.0), EPOCHS_SHORT,
                                "configs[4]: one sweep member, 10^5 bots, 20 % dead, light at (-40, 0)"),
 }
+def _rim_obstacles(orc, name, **over):
+    """The reference's obstacle examples verbatim leave their blob 2-3 units away from the obstacles: the first bot of
+    example_obstacle.cfg (seed 1000) touches a circle after ~220 000 steps, of example_gap.cfg a wall after ~390 000
+    (measured with the oracle) -- BASELINE configs[3]'s 120 000 steps never get there.  So that the obstacle force
+    sites are exercised in 10-step windows, these cases MOVE the obstacles to the rim of the placed blob (everything
+    else is the file): circles onto its leftmost / topmost / bottom-most bot, overlapping by 0.02; the two walls of
+    the gap file against the blob's left rim, the upper wall's inner corner diagonally off the leftmost bot."""
+    P, _ = _cfg(orc, name, **over)
+    tmp = orc.Sim(P, reset=True)
+    pos, rad = tmp.get("pos"), tmp.get("rad")
+    tmp.close()
+    if P.n_cir_obstacles:
+        picks = [int(np.argmin(pos[:, 0])), int(np.argmax(pos[:, 1])), int(np.argmin(pos[:, 1]))]
+        dirs = [(-1.0, 0.0), (0.0, 1.0), (0.0, -1.0)]
+        for k in range(min(int(P.n_cir_obstacles), 3)):
+            i, (ux, uy) = picks[k], dirs[k]
+            reach = float(P.r_cir_obs[k]) + float(rad[i]) - 0.02
+            P.x_cir_obs[k] = np.float32(pos[i, 0] + ux * reach)
+            P.y_cir_obs[k] = np.float32(pos[i, 1] + uy * reach)
+    if P.nobstacles:
+        # the blob's leftmost bot j sits DIAGONALLY off the upper wall's inner corner, 0.02 inside its reach (the corner
+        # branch, impl.cuh:757-779, is the one with powf); the bots above it meet that wall's right face; the lower
+        # wall keeps the file's gap width below the corner
+        j = int(np.argmin(pos[:, 0]))
+        x2 = np.float32(pos[j, 0] - 0.04)
+        gap = float(P.y1obs[1]) - float(P.y2obs[0])
+        for k in range(int(P.nobstacles)):
+            w = float(P.x2obs[k]) - float(P.x1obs[k])
+            P.x2obs[k] = x2
+            P.x1obs[k] = np.float32(x2 - w)
+        P.y1obs[1] = np.float32(pos[j, 1] + 0.04)
+        P.y2obs[0] = np.float32(float(P.y1obs[1]) - gap)
+    return P, None
+
+
 # Round 5: the cases that reach the DEVICE powf sites (obstacle and shadow tests, impl.cuh:214-229, 704-779).
 CASES.update({
+    "cfg4_obstacle_500_rim": (lambda orc: _rim_obstacles(orc, "example_obstacle.cfg", seed=1000), EPOCHS_RIM,
+                              "configs[3]'s example_obstacle.cfg, seed 1000, its three circles moved onto the rim of the "
+                              "placed blob (the file's own course is not reached within configs[3]'s 120 000 steps)"),
+    "cfg_gap_1000_rim": (lambda orc: _rim_obstacles(orc, "example_gap.cfg"), EPOCHS_RIM,
+                         "examples/example_gap.cfg, its two walls moved against the placed blob: faces and corners"),
+    "cfg4_obstacle_500_late": (lambda orc: _cfg(orc, "example_obstacle.cfg", seed=1000), (230000, 300000, 450000),
+                               "configs[3]'s example_obstacle.cfg verbatim, seed 1000, at the steps at which its blob is "
+                               "on the obstacle course (1-7 bots on a circle; the oracle walks 450 000 steps: fixture "
+                               "only, ~3 min)"),
     "cfg_gap_1000": (lambda orc: _cfg(orc, "example_gap.cfg"), EPOCHS_FULL,
                      "examples/example_gap.cfg verbatim (1000 bots, two rectangular obstacles: faces and corners)"),
     "cfg4_obstacle_500_shadow": (lambda orc: _cfg(orc, "example_obstacle.cfg", seed=1000, light_shadow=1), EPOCHS_FULL,
@@ -84,7 +129,10 @@ CASES.update({
                                  "checkIntersectionCircle for every bot (epoch 1195 crosses one)"),
 })
 # cases whose obstacles the device-powf bracket members (orclib.DEVPOWF_VARIANTS) can act on
-DEVPOWF_CASES = ("cfg4_obstacle_500", "cfg_gap_1000", "cfg4_obstacle_500_shadow")
+DEVPOWF_CASES = ("cfg4_obstacle_500", "cfg_gap_1000", "cfg4_obstacle_500_shadow", "cfg4_obstacle_500_rim",
+                 "cfg_gap_1000_rim", "cfg4_obstacle_500_late")
+# measured by the fixture generator only (the oracle walks 450 000 steps first); the GPU session skips them
+FIXTURE_ONLY_CASES = ("cfg4_obstacle_500_late",)
 CHEAP_CASES = ("cfg1_example_300", "cfg2a_dead_cells_100", "cfg4_obstacle_500", "cfg4_object_transport_201")
 
 

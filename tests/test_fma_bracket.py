@@ -155,8 +155,85 @@ def test_fixture_covers_every_baseline_config(fixture):
     for name, (_b, epochs, what) in fb.CASES.items():
         c = fixture["cases"][name]
         assert c["what"] == what and c["window"] == 10 and c["rtol"] == 1e-5
-        for v in ("fma", "fma_powf"):
+        for v in ("fma", "fma_powf") + (orc_devpowf_variants() if name in fb.DEVPOWF_CASES else ()):
             assert [r["epoch"] for r in c["candidates"][v]] == list(epochs)
+
+
+def orc_devpowf_variants():
+    from oracle import orclib
+    return orclib.DEVPOWF_VARIANTS
+
+
+def test_device_powf_members_touch_nothing_but_the_obstacle_sites(orc):
+    """Round 5: oracle/libpb_oracle_devpowf{,_ulp}.so model the reference's DEVICE powf calls
+    (particlebot_kernel_impl.cuh:214-229 shadow test, :704-705, :719 circles, :757-779 rectangle corners) as
+    exp2f(y*log2f(x)) / as the correctly rounded result moved by -1 / 0 / +1 ulp.  Nothing else may differ: no FMA
+    anywhere, the host side bit-identical, a configuration without obstacles bit-identical for 300 steps, and on
+    a circle contact the force differs from the oracle's in the last bits only."""
+    here = os.path.dirname(orc.__file__)
+    for v, tag in (("devpowf", b"devpowf"), ("devpowf_ulp", b"devpowf_ulp"), ("cuda_like", b"fma+powf+devpowf")):
+        assert orc.variant_lib(v).orc_build_variant() == tag
+    for v in ("devpowf", "devpowf_ulp"):
+        assert fma_functions(os.path.join(here, f"libpb_oracle_{v}.so")) == {}
+    # no obstacles: the same bits
+    ref = None
+    for v in (None, "devpowf", "devpowf_ulp"):
+        P = orc.load_cfg(fb.EX("example.cfg"), phase_std=0.0, max_time=1e9)
+        sim = orc.Sim(P, reset=True, variant=v)
+        sim.run(300)
+        st = [sim.get(k) for k in ("pos", "vel", "rad", "absForce_a", "absForce_r")]
+        sim.close()
+        if ref is None:
+            ref = st
+        else:
+            for a, b in zip(ref, st):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), v
+    # circles on the rim of the blob: placement identical, the first step's repulsion sums differ in the last bits
+    P, _ = fb.CASES["cfg4_obstacle_500_rim"][0](orc)
+    sims = {v: orc.Sim(P, reset=True, variant=v) for v in (None, "devpowf", "devpowf_ulp")}
+    placed = sims[None].get("pos")
+    for v, sim in sims.items():
+        assert np.array_equal(sim.get("pos").view(np.uint32), placed.view(np.uint32))
+    touched = {v: np.zeros(sims[None].n, bool) for v in ("devpowf", "devpowf_ulp")}
+    for _ in range(20):
+        for sim in sims.values():
+            sim.run(1)
+        fr = {v: sim.get("absForce_r") for v, sim in sims.items()}
+        for v in touched:
+            diff = fr[v].view(np.uint32) != fr[None].view(np.uint32)
+            touched[v] |= diff
+            if diff.any():
+                rel = np.abs(fr[v][diff] - fr[None][diff]) / np.abs(fr[None][diff])
+                assert rel.max() < 1e-3, (v, rel.max())   # (a sum of a few small terms: last bits of each)
+    for v, t in touched.items():
+        assert 1 <= int(t.sum()) <= 60, (v, int(t.sum()))   # the bots on a circle and, later, their neighbours
+    for sim in sims.values():
+        sim.close()
+
+
+def test_what_the_device_powf_bracket_says(fixture):
+    """The statements DESIGN.md section 8 quotes from the fixture.  (a) The reference's obstacle files verbatim never
+    reach their obstacles inside a window of the first 3 100 steps -- nor inside BASELINE configs[3]'s 120 000: the
+    device-powf members are the oracle there, bit for bit.  (b) Where bots ARE on the obstacles (the file's own course
+    after 230 000 - 450 000 steps; the rim cases) a non-correctly-rounded powf moves no bot beyond 1e-5 in ten steps,
+    stays an order of magnitude below what FMA contraction does at the 99th percentile, and every member together
+    (`cuda_like`) is the FMA + __powf member within noise.  (c) light_shadow: the shadow test is a yes/no decision
+    taken once per 1 200 steps; neither model flips one here."""
+    s = fixture["summary"]
+    for case in ("cfg4_obstacle_500", "cfg_gap_1000", "cfg4_obstacle_500_shadow"):
+        for v in ("devpowf", "devpowf_ulp"):
+            assert s[case][v]["max_max"] == 0.0 and s[case][v]["flips_total"] == 0, (case, v)
+    touched = 0
+    for case in ("cfg4_obstacle_500_rim", "cfg4_obstacle_500_late", "cfg_gap_1000_rim"):
+        for v in ("devpowf", "devpowf_ulp"):
+            r = s[case][v]
+            assert r["flips_total"] == 0 and r["max_max"] <= 1e-6 and r["p99_max"] <= 1e-7, (case, v, r)
+            assert r["p99_max"] <= 0.25 * s[case]["fma"]["p99_max"], (case, v)
+            touched += r["max_max"] > 0.0
+        a, b = s[case]["cuda_like"], s[case]["fma_powf"]
+        assert a["flips_total"] <= b["flips_total"] + 1 and a["p99_max"] <= 2 * b["p99_max"] + 1e-8, (case, a, b)
+    assert touched >= 4   # both circle cases, both members (the gap's corner contact lasts three steps: last bits of
+                          # absForce_r only, no position bit)
 
 
 def test_what_the_bracket_says(fixture):
@@ -168,8 +245,12 @@ def test_what_the_bracket_says(fixture):
         for v, recs in c["candidates"].items():
             if v == "order":
                 # the ORDER of additions alone (exact terms, contacts added last) moves no bot beyond 1e-5, anywhere
-                assert all(r["window"]["flips"] == 0 and r["window"]["p99"] <= 1e-7 for r in recs), (name, recs)
+                # (p99 <= 1e-7 in the first 3 100 steps; 2.2e-7 once the blob is spread over the obstacle course)
+                lim = 1e-6 if name == "cfg4_obstacle_500_late" else 1e-7
+                assert all(r["window"]["flips"] == 0 and r["window"]["p99"] <= lim for r in recs), (name, recs)
                 continue
+            if v in ("devpowf", "devpowf_ulp", "cuda_like"):
+                continue   # test_what_the_device_powf_bracket_says
             for r in recs:
                 w = r["window"]
                 # 10-step teacher-forced window: the bulk agrees far inside 1e-5 ...
@@ -184,7 +265,11 @@ def test_what_the_bracket_says(fixture):
                 bot_windows += c["bots"]
                 # un-resynchronised, the 99th percentile holds 1e-5 for at least 25 steps (SURVEY.md 0.5
                 # measured 10-20 on its probe) ...
-                assert r["break_p99"] is None or r["break_p99"] >= 25, (name, v, r)
+                # (round 5's cases -- the 1000-bot gap file, walls pushing into a freshly placed blob, a blob strung out
+                #  over the obstacle course -- are looser: 21 at the least; the round-4 cases 26)
+                old = name in ("cfg1_example_300", "cfg2a_dead_cells_100", "cfg2b_dead_cells_10k", "cfg3_arena_crop_10k",
+                               "cfg4_obstacle_500", "cfg4_object_transport_201", "cfg5_member_1e5_dead20")
+                assert r["break_p99"] is None or r["break_p99"] >= (25 if old else 20), (name, v, r)
                 # ... and a blob of >= 10^4 bots has its first bot beyond 1e-5 within 20 steps and 1 % of
                 # them within 70 (the jammed lattice never leaves 1e-5; small blobs take 26 to > 100 steps)
                 if name in ("cfg2b_dead_cells_10k", "cfg5_member_1e5_dead20"):
@@ -205,7 +290,7 @@ def test_gpu_box_record_agrees_with_this_fixture(fixture):
     bracket is a deterministic function of (source, gcc), not of the machine -- and the record must hold what
     DESIGN.md section 8 quotes for the product's tolerance kernel."""
     rec = json.load(open(os.path.join(HERE, "golden", "fma_bracket", "hip_streamlined.json")))
-    assert set(rec["cases"]) == set(fixture["cases"])
+    assert set(rec["cases"]) == set(fixture["cases"]) - set(fb.FIXTURE_ONLY_CASES)
     flips = {"hip_streamlined": 0, "fma": 0}
     for name, c in rec["cases"].items():
         assert c["candidates"]["fma"] == fixture["cases"][name]["candidates"]["fma"], name
@@ -214,4 +299,4 @@ def test_gpu_box_record_agrees_with_this_fixture(fixture):
             for r in c["candidates"][cand]:
                 assert r["window"]["median"] <= 1e-7 and r["window"]["p99"] <= 1e-6
     # the tolerance kernel flips no more bots than the FMA build of the reference's own arithmetic does (+ slack)
-    assert flips["fma"] == 18 and flips["hip_streamlined"] <= 2 * flips["fma"], flips
+    assert flips["fma"] == 20 and flips["hip_streamlined"] <= 2 * flips["fma"], flips   # (round 4: 18; + the gap rim case's 2)

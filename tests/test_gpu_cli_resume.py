@@ -311,4 +311,4 @@ def test_csv_dir_never_writes_a_silently_shortened_file(tmp_path, capfd):
     assert p.run() > 0
     text = open(d2 / "member_000001.csv").read()      # complete BEFORE close(): the run closed it
     p.close()
-    assert text.startswith("Seed, 5201\n") and text.count("\n") == 2 + 6   # seed, header, rows at 0, 6, ... 30
+    assert text.startswith("Seed, 5201\n") and text.count("\n") == 2 + 7   # seed, header, rows at 0, 0.01 (the reference's gate passes both), 6 ... 30

@@ -50,7 +50,7 @@ def _write_results():
                        "summary": {n: fb.summarise(r) for n, r in _results.items()}, "cases": _results}, f, indent=1)
 
 
-@pytest.mark.parametrize("case", list(fb.CASES))
+@pytest.mark.parametrize("case", [c for c in fb.CASES if c not in fb.FIXTURE_ONLY_CASES])
 def test_streamlined_kernel_inside_the_bracket(pb, orc, case):
     orc.lib().orc_set_num_threads(orc.usable_cpus())
     orc.variant_lib("fma").orc_set_num_threads(orc.usable_cpus())

@@ -38,8 +38,11 @@ def main():
     pb.legacy.cudaInit(0, None)
     n = args.bots
     variants = args.variants.split(",")
-    pos = (bench.square_lattice(n, args.pitch) if args.lattice == "square"
-           else bench.hex_lattice(n, np.float32(args.pitch)))
+    if args.lattice == "blob":   # the reference's kind of initial state: a random blob (pb_placement fastblob)
+        pos, _ = bench.BlobPlacement(n).get()
+    else:
+        pos = (bench.square_lattice(n, args.pitch) if args.lattice == "square"
+               else bench.hex_lattice(n, np.float32(args.pitch)))
     sims = {}
     for v in variants:
         sp, keep = bench.workload_params(n, seed=1)
