@@ -41,11 +41,23 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert 0 < e2e["value_end_to_end"] and el["value_end_to_end"] == e2e["value_end_to_end"]
     assert e2e["pipeline_rank0"][0]["sub_batches"] == 1 and "sims_per_s" not in el
     # short timed regions carry a second, >= 100 ms figure
-    assert d["device_ms_timed_region"] < 50.0 and d["value_long"] > 0 and d["roofline"]["frac_long"] > 0
-    assert d["steps_long"] * d["roofline"]["avg_launch_us_long"] * 1e-3 >= 90.0   # (sized from the short region's pace)
+    assert d["device_ms_timed_region"] < 50.0 and d["value_long"] > 0 and d["roofline"]["frac_dead_sum_long"] > 0
+    assert d["steps_long"] * d["roofline"]["avg_launch_us_dead_sum_long"] * 1e-3 >= 90.0   # (sized from the short region's pace)
     assert "glibc" in d["host"] and d["host"]["cpus"] >= 1
-    assert "frac_both_sums" in d["roofline"] and "alg_bytes_note" in d["roofline"]
-    assert 0 < d["roofline"]["frac_both_sums"] <= d["roofline"]["frac_long"] * 1.05
+    # like for like: `frac` is the kernel that writes everything collideD writes (the both_sums leg) at
+    # 64 B; the kernel `value` runs is priced at the 56 B it moves; both recomputable from the line itself
+    assert "alg_bytes_note" in r and "collideD" in r["frac_is"] and "hbm_target_note" in r
+    b = d["both_sums"]
+    us_b = b.get("us_per_step_long", b["us_per_step"])
+    assert abs(r["avg_launch_us"] - us_b) < 1e-9 and r["algorithmic_bytes_per_launch"] == 64.0 * 200000
+    assert abs(r["achieved"] - 64.0 * 200000 / (us_b * 1e-6) / 1e9) / r["achieved"] < 1e-9
+    assert r["frac"] == r["frac_both_sums"] and "false, true>" in r["kernel"]
+    ds = r["dead_sum"]
+    assert ds["algorithmic_bytes_per_launch"] == 56.0 * 200000 and abs(ds["frac"] - r["frac_dead_sum"]) < 1e-15
+    assert abs(ds["achieved"] - 56.0 * 200000 / (ds["avg_launch_us"] * 1e-6) / 1e9) / ds["achieved"] < 1e-9
+    assert abs(r["frac_dead_sum_priced_at_64"] * 56.0 / 64.0 - r["frac_dead_sum"]) < 1e-12
+    assert 0 < r["frac"] <= r["frac_dead_sum_priced_at_64_long"] * 1.05
+    assert d["config"]["force_sums_note"].endswith("roofline.frac")
     la = d["large_arena"]
     assert la["bots"] == 8_000_000 and la["finite_at_end"] and la["us_per_step"] > 0 and la["us_per_step_long"] > 0
     assert la["device_prewarm_ms"] >= 100.0

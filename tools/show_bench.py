@@ -10,6 +10,14 @@ r = d.get("roofline")
 if r:
     print("roofline frac", round(r["frac"], 4), "achieved", round(r["achieved"], 1), r["unit"], "avg_launch_us",
           round(r.get("avg_launch_us", 0), 2), "clock", r.get("shader_clock_mhz"), "traffic", r.get("traffic"))
+    if "frac_dead_sum" in r:
+        ds = r.get("dead_sum", {})
+        print("  frac (both sums, 64 B)", round(r["frac"], 4), "| frac_dead_sum (56 B)", round(r["frac_dead_sum"], 4),
+              "(long", round(r.get("frac_dead_sum_long", 0), 4), ") avg_launch_us", round(ds.get("avg_launch_us", 0), 2),
+              "long", round(ds.get("avg_launch_us_long", 0), 2), "| priced at 64 as rounds 1-4:",
+              round(r.get("frac_dead_sum_priced_at_64", 0), 4), "| valu_frac_of_datasheet",
+              r.get("valu_frac_of_datasheet") and round(r["valu_frac_of_datasheet"], 3), "both sums",
+              r.get("valu_frac_of_datasheet_both_sums") and round(r["valu_frac_of_datasheet_both_sums"], 3))
     v = r.get("valu")
     if v:
         print("valu: per wave", round(v["valu_insts_per_wave"]), "trans", round(v["trans_per_wave"]),
