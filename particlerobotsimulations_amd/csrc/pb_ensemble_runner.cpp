@@ -3,12 +3,13 @@
 // with one ncclAllGather over RCCL/xGMI (include/particlebot_ensemble.h).
 //
 //   particlebot_ensemble <config.cfg> --members M [--seed0 S] [--set NAME VALUE]...
-//                        [--sweep KEY V1 V2 ...] [--out FILE] [--csv-dir DIR] [--sub-batch B] [--host-threads T]
+//                        [--sweep KEY V1 V2 ...]... [--out FILE] [--csv-dir DIR] [--sub-batch B] [--host-threads T]
 //                        [--checkpoint DIR | --resume DIR] [--rendezvous FILE]
 //
 // Launch with any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (torchrun), OMPI_COMM_WORLD_* or
 // SLURM_PROCID / SLURM_NTASKS / SLURM_LOCALID, or by hand:  RANK=r WORLD_SIZE=N LOCAL_RANK=r ...
-// Member k (seed seed0 + k, sweep value V[k mod #V]) runs on rank k mod N.  A rank's members run through the
+// Member k (seed seed0 + k, sweep value V[k mod #V] of every --sweep, `--sweep seed ...` replacing the seed) runs on
+// rank k mod N.  A rank's members run through the
 // placement/stepping pipeline (pbEnsemblePipeline*): sub-batches of B members (0: all at once, the default; -1: whole
 // placement rounds of the producer pool that bring a sub-batch to ~3 x 10^6 bots -- for members of ~10^5 bots and
 // more), the host placing the next ones
@@ -237,8 +238,7 @@ static bool fetchIdFile(const std::string &path, ncclUniqueId *id, double timeou
 int main(int argc, char **argv) {
   std::string cfgPath, outPath, rendezvous, ckptDir, csvDir;
   std::vector<std::pair<std::string, std::string>> sets;
-  std::string sweepKey;
-  std::vector<std::string> sweepVals;
+  std::vector<std::pair<std::string, std::vector<std::string>>> sweeps;  // --sweep may be given several times
   int members = 32, subBatch = 0, hostThreads = 0;
   bool resume = false, rendezvousTest = false;
   long seed0 = 1000;
@@ -259,11 +259,11 @@ int main(int argc, char **argv) {
       sets.emplace_back(argv[i + 1], argv[i + 2]);
       i += 2;
     } else if (!strcmp(argv[i], "--sweep") && i + 2 < argc) {
-      sweepKey = argv[++i];
-      while (i + 1 < argc && strncmp(argv[i + 1], "--", 2) != 0) sweepVals.push_back(argv[++i]);
+      sweeps.emplace_back(argv[++i], std::vector<std::string>());
+      while (i + 1 < argc && strncmp(argv[i + 1], "--", 2) != 0) sweeps.back().second.push_back(argv[++i]);
     } else if (argv[i][0] != '-' && cfgPath.empty()) cfgPath = argv[i];
     else {
-      fprintf(stderr, "usage: %s <config.cfg> --members M [--seed0 S] [--set NAME VALUE]... [--sweep KEY V1 V2 ...] "
+      fprintf(stderr, "usage: %s <config.cfg> --members M [--seed0 S] [--set NAME VALUE]... [--sweep KEY V1 V2 ...]... "
                       "[--out FILE] [--csv-dir DIR] [--sub-batch B] [--host-threads T] [--checkpoint DIR | --resume DIR] "
                       "[--rendezvous FILE (single host)]\n", argv[0]);
       return 2;
@@ -359,7 +359,9 @@ int main(int argc, char **argv) {
   std::vector<std::string> over;
   for (int k = rank; k < members; k += world) {
     std::string o = "seed\n" + std::to_string(seed0 + k);
-    if (!sweepKey.empty() && !sweepVals.empty()) o += "\n" + sweepKey + "\n" + sweepVals[(size_t)k % sweepVals.size()];
+    // (in the order given; a later key wins, so `--sweep seed ...` replaces seed0 + k)
+    for (auto &sw : sweeps)
+      if (!sw.first.empty() && !sw.second.empty()) o += "\n" + sw.first + "\n" + sw.second[(size_t)k % sw.second.size()];
     over.push_back(o);
   }
   std::vector<const char *> overPtr;

@@ -149,3 +149,63 @@ def test_config5_slice_statistic_is_the_same_with_the_tolerance_kernel(tmp_path)
     # ... the fractions stay apart by far more than that, and member by member the difference is inside the seed spread
     assert np.abs(m_t - m_e).max() <= 0.1 * np.abs(np.diff(m_e)).min()
     assert np.abs(p_t - p_e).max() <= 5 * s_e.max(), (np.abs(p_t - p_e).max(), s_e.max())
+
+
+def test_config5_whole_sweep_1024_members_reproduces_the_recorded_statistic(tmp_path, orc):
+    """BASELINE configs[4] WHOLE under the driver's eyes (until now a builder soak): all 1 024
+    members -- 64 dead fractions 0 ... 0.40 x 16 seeds of examples/example_dead_cells.cfg at 10^5 bots, light at
+    (-40, 0), 12 000 timesteps -- in ONE invocation of bin/particlebot_ensemble (--sub-batch -1: two lanes of
+    sub-batches, the RCCL gather with a world of one), ~85 s on one MI355X.  The members are those of
+    results/cfg5_full_sweep.json (round 1: four runs of 256 members, seeds 1000+k / 2000+k / 3000+k / 4000+k, dead
+    count nDead[k mod 64]; here `--sweep seed ...` next to `--sweep nDead ...`), and because every exact kernel of every
+    round is bit-identical to the oracle the statistic must be the recorded one TO THE LAST DIGIT: every member's
+    progress toward the light (fp32 difference of the distance column), hence every per-fraction mean.  Also: the
+    reference's clock and row count, the monotone decline over all 64 fractions, a device-bound pipeline on a box with
+    >= 16 usable CPUs, and three random members replayed on the oracle."""
+    rec = json.load(open(os.path.join(ROOT, "results", "cfg5_full_sweep.json")))
+    dead = [int(x) for x in rec["nDead"]]
+    assert len(dead) == 64 and dead[0] == 0 and dead[-1] == 40000
+    members = 1024
+    seeds = [1000 * (k // 256 + 1) + k % 256 for k in range(members)]
+    di = 1.0   # (the record was made with the file's own dump interval: the first and the last row are the same states)
+    sets = {"nCells": "100000", "light_x": "-40", "light_y": "0", "max_time": "120", "dump_interval": str(di)}
+    out = tmp_path / "rows.bin"
+    cmd = [ENS, EX("example_dead_cells.cfg"), "--members", str(members), "--seed0", "1000", "--out", str(out), "--sub-batch", "-1"]
+    for k, v in sets.items():
+        cmd += ["--set", k, v]
+    cmd += ["--sweep", "nDead"] + [str(d) for d in dead] + ["--sweep", "seed"] + [str(x) for x in seeds]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29449")
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    info = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    rows = np.fromfile(out, np.float32).reshape(members, info["rows_per_member"], 4)
+    want_t, want_steps = expected_row_times(120.0, di)
+    assert info["members"] == members and info["bots_per_member"] == 100000 and info["n_gpus"] == 1
+    assert info["steps_per_member"] == want_steps and 11900 < want_steps <= 12001
+    assert rows.shape == (members, len(want_t), 4) and np.isfinite(rows).all()
+    assert all(np.array_equal(rows[k, :, 0], want_t) for k in range(members))       # one clock, the reference's
+    assert len({tuple(np.round(r[0, 1:3], 5)) for r in rows}) == members            # 1 024 different blobs
+    progress = rows[:, 0, 3] - rows[:, -1, 3]                                        # fp32, as the record was made
+    assert progress.dtype == np.float32
+    by_f = np.zeros(64)
+    worst = 0.0
+    for j, d in enumerate(dead):
+        mine = progress[j::64]                         # k = j, j + 64, ...: batch-major, as recorded
+        want = np.array(rec["progress"][str(d)], np.float32)
+        assert mine.shape == want.shape == (16,)
+        worst = max(worst, float(np.abs(mine.astype(np.float64) - want).max()))
+        assert np.array_equal(mine, want), (d, mine, want)
+        by_f[j] = mine.astype(np.float64).mean()
+        assert by_f[j] == want.astype(np.float64).mean()
+    assert np.all(np.diff(by_f) < 0), by_f                                           # strictly monotone over all 64
+    assert abs(by_f[0] - 0.08422) < 1e-4 and abs(by_f[-1] - 0.0215) < 1e-3           # results/cfg5_full_sweep.md
+    pl = info["pipeline_rank0"]
+    usable = orc.usable_cpus()
+    print(f"configs[4] whole: 1 024 members x 10^5 bots x {want_steps} steps in {info['wall_s']:.1f} s "
+          f"({info['particle_steps_per_s']:.3g} particle-steps/s end to end), pipeline {pl}; usable CPUs {usable}; "
+          f"statistic equal to results/cfg5_full_sweep.json to the last digit (max |diff| {worst})")
+    if usable >= 16:
+        assert pl["bound"] == "device", pl
+    assert pl["lanes"] == 2 and pl["sub_batches"] >= 30
+    over_of = lambda k: dict(seed=seeds[k], nDead=dead[k % 64], nCells=100000, light_x=-40.0, light_y=0.0)
+    replay_three_members(orc, np.random.default_rng(9), "example_dead_cells.cfg", members, over_of, di, rows)
