@@ -1273,7 +1273,8 @@ def main():
         ens_leg, _ = measure_ensemble(pb, "ensemble4", 32, min(max(args.steps, 200), 4000), 20, args.prewarm_ms, rank,
                                       world, dist, torch, end_to_end=not args.no_end_to_end, e2e_steps=args.e2e_steps,
                                       strong_total=256)
-        warm = DevicePrewarm(pb, min(n, 1_000_000), args.pitch, args.prewarm_ms if rank == 0 and world == 1 else 0.0)
+        # (rank 0 goes on to the both_sums leg -- `roofline.frac` -- at every world size; the other ranks have no leg left)
+        warm = DevicePrewarm(pb, min(n, 1_000_000), args.pitch, args.prewarm_ms if rank == 0 else 0.0)
     if rank == 0:
         launches = (s1["fused_launches"] - s0["fused_launches"]) + (s1["plain_launches"] - s0["plain_launches"])
         value = world * n * args.steps / wall
