@@ -151,6 +151,21 @@ static inline bool pbFastMathAllowed(const PbDevParams &d) {
   return ok;
 }
 
+// Precondition of the both-sums throughput form's attraction magnitude (pbPairEvalXY<FAST, true>): the root of
+// |term|^2 comes from pbRootNewton, exact for 0 and for [2^-96, FLT_MAX).  A non-contact term is the 2.5 N band or
+// A * n / gap^2 with gap^2 < 2^27 (above) and max(|nx|, |ny|) >= 2^-0.5, so |term|^2 >= A^2 * 2^-55: inside the domain
+// when every attraction constant a pair can see is 0 or >= 2^-20 (the reference's default is 4e-4 = 2^-11.3).  A batch
+// that fails it runs that form's plain IEEE path.
+static inline bool pbAttractionMagnitudeSafe(const PbDevParams &d) {
+  auto okA = [](float a) { return a == 0.0f || a >= 0x1p-20f; };
+  bool ok = okA(d.attraction);
+  if (d.nDead == -1) {
+    const float a1 = d.attraction * d.attractionFactor;
+    ok = ok && okA(a1) && okA(a1 * d.attractionFactor);
+  }
+  return ok;
+}
+
 // the layout scripts and reference-built callers rely on (particlebot_kernel.cuh:58-120)
 #include <cstddef>
 // (float2/uint2 are 8-byte aligned in HIP exactly as in CUDA, hence the hole after numCells)
@@ -338,15 +353,24 @@ PB_DEV void pbDiv2Fast(float a, float b, float d, float &qa, float &qb) {
 // quotients differ (2 of 2^47).  In those cases e = 1 - dist*s is exactly 2^-24, which sends the wave to the
 // v_rcp_f32 form (0 mismatches over the same 2^47).  Domain: as pbSqrtFast / pbDiv2Fast (d2 == 0 or >= 2^-88
 // in the kernel; numerators +0 or >= 2^-100).
-PB_DEV void pbDistUnitFast(float rx, float ry, float d2, float &dist, float &nx, float &ny) {
-  const float s = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(d2), 0.0f, 0x1.fffffep127f);
+// The root part on its own: sqrtf(x) for x == 0 or 2^-96 <= x < FLT_MAX from ONE v_rsq_f32 and ONE Newton step; s = the
+// (clamped) reciprocal root it started from, for callers that go on to the reciprocal.  5 VALU + 1 transcendental
+// against pbSqrtFast's 8 + 1.
+PB_DEV float pbRootNewton(float x, float &s) {
+  s = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(x), 0.0f, 0x1.fffffep127f);
   const float h = 0.5f * s;
-  float y = d2 * s;
+  float y = x * s;
   // ONE Newton step (round 3; two until then): exact for every float that is 0 or in [2^-96, FLT_MAX) --
   // tools/one_newton_root_test.hip, profiles/r3_one_newton_root_exhaustive.txt: 1 879 048 193 values, 0 differ from
-  // sqrtf; pbSelfTest repeats it on this function at the start of every GPU test session
-  const float e = __builtin_fmaf(-y, y, d2);
-  y = __builtin_fmaf(e, h, y);
+  // sqrtf; pbSelfTest repeats it on pbDistUnitFast (which is this function + the unit vector) at the start of every
+  // GPU test session
+  const float e = __builtin_fmaf(-y, y, x);
+  return __builtin_fmaf(e, h, y);
+}
+
+PB_DEV void pbDistUnitFast(float rx, float ry, float d2, float &dist, float &nx, float &ny) {
+  float s;
+  const float y = pbRootNewton(d2, s);
   dist = y;
   const float er = __builtin_fmaf(-y, s, 1.0f);
   float r = __builtin_fmaf(er, s, s);
@@ -603,10 +627,14 @@ struct PbPairXY {
   float tx, ty;
 };
 
-template <bool FAST, class VelFetch, class PushRep>
+// WANT_A (round 5: the throughput form that keeps BOTH sums): also return, in magA, the magnitude of the term of a
+// lane that is NOT in contact -- length(tempforce) of the attraction branches (impl.cuh:580-592), the root of the
+// uncontracted dot product of the rounded components, as pbPairEvalK forms it -- and the lane's contact flag; a
+// contact's magnitude still goes through pushRep.  magA of a contact lane or of a lane that is not live is garbage.
+template <bool FAST, bool WANT_A = false, class VelFetch, class PushRep>
 PB_DEV PbPairXY pbPairEvalXY(const PbContactK &P, bool live, float ax, float ay, float avx, float avy, float ra,
                              float bx, float by, float rb, VelFetch velB, float attraction, float slope,
-                             PushRep pushRep) {
+                             PushRep pushRep, float *magA = nullptr, bool *isContact = nullptr) {
   const float near1 = 0.0009f, near2 = 0.0019f, fmin_attr = 2.5f;
   const float rx = bx - ax, ry = by - ay;
   const float d2 = pbDot(rx, ry, rx, ry);
@@ -657,6 +685,19 @@ PB_DEV PbPairXY pbPairEvalXY(const PbContactK &P, bool live, float ax, float ay,
       tx = contact ? cx : tx;
       ty = contact ? cy : ty;
     }
+  }
+  if (WANT_A) {
+    const float m2 = pbDot(tx, ty, tx, ty);
+    float mag;
+    if (FAST) {
+      // (no check for a tiny m2: the caller only takes the FAST path for batches that pass pbAttractionMagnitudeSafe)
+      float s;
+      mag = pbRootNewton(m2, s);
+    } else {
+      mag = sqrtf(m2);
+    }
+    *magA = mag;
+    *isContact = contact;
   }
   PbPairXY r;
   r.tx = tx;

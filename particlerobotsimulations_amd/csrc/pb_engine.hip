@@ -718,9 +718,11 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
   S->hP.resize(nsims);
   S->payload = params[0].nDead == -1;
   S->fastOk = true;
+  S->magOk = true;
   for (int k = 0; k < nsims; k++) {
     pbFlattenParams(S->hP[k], params[k], wallHalf);
     S->fastOk = S->fastOk && pbFastMathAllowed(S->hP[k]);
+    S->magOk = S->magOk && pbAttractionMagnitudeSafe(S->hP[k]);
     S->anyConstrained = S->anyConstrained || S->hP[k].constrained_contraction != 0u;
   }
   // A/B switches for tools/ab_bench.py: honoured only under PB_ALLOW_ENV_OVERRIDES=1 and through the

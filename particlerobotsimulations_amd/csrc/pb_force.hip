@@ -74,7 +74,8 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
   // wave-uniform choice: the fast exact forms need every lane's coordinates away from zero
   using OffT = typename std::conditional<BIG, uint64_t, uint32_t>::type;
   static_assert(ASUM || (FLAT && NB == 1), "the dead-sum form exists for the branch-free sweeps only");
-  constexpr bool REPLIST = !ASUM && L == 1;  // (L > 1: magnitudes are rooted inside the contact block)
+  // (L > 1: magnitudes are rooted inside the contact block; the both-sums throughput form has the list since round 5)
+  constexpr bool REPLIST = L == 1 && FLAT && NB == 1 && (!ASUM || PB_ASUM_XY);
   __shared__ float repLds[REPLIST ? (PB_REP_CAP + 1) * TILE : 1];
   float *const repCol = &repLds[REPLIST ? threadIdx.x : 0];
   if (FLAT && fastOk && __all(pbLaneFastMathOk(me.x, me.y)))
@@ -112,7 +113,9 @@ void launchForceT(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int 
   const uint32_t perXcd = (L == 1 && tiles >= 64u) ? cdiv(tiles, 8u) : 0u;
   const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
   constexpr int NB = (FLAT && L == 1 && !BIG && ASUM) ? PB_THROUGHPUT_NB : 1;
-  const int fastOk = (S->variant >= 2 && S->fastOk) ? 1 : 0;
+  // (the both-sums throughput form roots its attraction magnitudes without a domain check: pbAttractionMagnitudeSafe)
+  const bool magNeeded = ASUM && FLAT && L == 1 && PB_ASUM_XY;
+  const int fastOk = (S->variant >= 2 && S->fastOk && (!magNeeded || S->magOk)) ? 1 : 0;
   // (debugLdsBytes: an occupancy experiment -- unused dynamic LDS that only limits workgroups per CU)
   hipLaunchKernelGGL((k_force<PAYLOAD, FLAT, L, NB, BIG, ASUM>), grid, dim3(TILE), S->debugLdsBytes, S->stream, S->dP,
                      S->pr[c], S->vel[c], S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c],

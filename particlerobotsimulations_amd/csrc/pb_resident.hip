@@ -24,7 +24,7 @@ __global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict
   constexpr int CAP = 1024 / L;
   __shared__ float4 sPr[2][CAP + 1];  // +1: the sweep prefetches one slot past a range
   __shared__ float2 sVel[2][CAP + 1];
-  constexpr bool REPLIST = !ASUM && L == 1;
+  constexpr bool REPLIST = L == 1 && (!ASUM || PB_ASUM_XY);  // (as k_force: the one-lane-per-bot sweep parks contact magnitudes)
   __shared__ float repLds[REPLIST ? (PB_REP_CAP + 1) * 1024 : 1];
   float *const repCol = &repLds[REPLIST ? threadIdx.x : 0];
   const PbDevParams &P = params[blockIdx.x];
@@ -149,8 +149,9 @@ void launchResidentT(pbSim *S, float dt, float t0, int m, int lightWave) {
 }  // namespace
 
 void pbLaunchResident(pbSim *S, float dt, float t0, int m, int lightWave) {
-  const bool fast = S->variant >= 2 && S->fastOk;
   const bool asum = attractionSumsKept(S);
+  // (with both sums kept the one-lane-per-bot sweep roots its attraction magnitudes without a domain check)
+  const bool fast = S->variant >= 2 && S->fastOk && (!asum || S->magOk);
 #define PB_RESL(PL, FA)                                                   \
   do {                                                                    \
     if (asum) launchResidentT<PL, FA, true>(S, dt, t0, m, lightWave);     \

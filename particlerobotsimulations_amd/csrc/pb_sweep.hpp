@@ -30,6 +30,9 @@
 // (64 VGPRs, 28 spilled), 120.8 at 7 (72), 119.8 at 6 (80), 121.4 at 5 (81, no bound) against 114.0
 // for NB = 1 (63 VGPRs, 8 waves/SIMD): waves, not ILP inside a wave, are what fills the VALU pipe.
 
+#ifndef PB_ASUM_XY
+#define PB_ASUM_XY 1  // throughput form with both sums: 1 = the dead-sum trip + the attraction magnitude (round 5), 0 = pbPairEvalK
+#endif
 #ifndef PB_LAZY_VEL
 #define PB_LAZY_VEL 1  // (0: the round-2 form, the neighbour's velocity prefetched with every posrad)
 #endif
@@ -284,8 +287,11 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
     const OffT selfOff = (OffT)s * 16u;
     auto at = [&](OffT off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
     auto vat = [&](OffT off) __attribute__((always_inline)) { return *(const float2 *)(velBytes + (off >> 1)); };
+    // (round 5: the form that keeps both sums parks its contact magnitudes in LDS too; PB_ASUM_XY 0 = the former
+    //  pbPairEvalK + pbPairAdd path, kept for A/B)
+    constexpr bool REPL = !ASUM || PB_ASUM_XY;
     PbRepList<FAST, PB_REP_CAP, REPSTRIDE> rep;
-    if (!ASUM) rep.init(repCol);
+    if (REPL) rep.init(repCol);
     // (64-bit address arithmetic with a constant displacement: the displacement becomes the load's
     //  immediate offset, so the look-ahead loads need no address instructions of their own)
 #if PB_SWEEP_EXPERIMENT >= 2
@@ -319,10 +325,24 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
       const float bx[1] = {q.x}, by[1] = {q.y}, rb[1] = {q.z};
       const float A[1] = {PAYLOAD ? attraction0 * q.w * att1 : attraction0};
       const float K[1] = {PAYLOAD ? pbBandSlope(A[0]) : slope0};
-      if (ASUM) {
+      if (ASUM && !PB_ASUM_XY) {
         PbPairTerm t[1];
         pbPairEvalK<FAST, 1>(CK, live, me.x, me.y, v.x, v.y, me.z, bx, by, rb, A, K, [&](int) { return velOf(); }, t);
         pbPairAdd(live[0], t[0], F);
+      } else if (ASUM) {
+        // both sums: the dead-sum trip + the magnitude of the lane's attraction term (Sum|F_attr| in list order, as
+        // absforce_a += length(tempforce), impl.cuh:580-592); contact magnitudes through the LDS list as below
+        float magA;
+        bool contact;
+        const PbPairXY t = pbPairEvalXY<FAST, true>(CK, live[0], me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, velOf, A[0],
+                                                    K[0], [&](bool mine, float m2) { rep.push(mine, m2, F.fr); }, &magA,
+                                                    &contact);
+        if (live[0]) {
+          asm volatile("");
+          F.fx += t.tx;
+          F.fy += t.ty;
+          if (!contact) F.fa += magA;
+        }
       } else {
         const PbPairXY t = pbPairEvalXY<FAST>(CK, live[0], me.x, me.y, v.x, v.y, me.z, q.x, q.y, q.z, velOf, A[0],
                                               K[0], [&](bool mine, float m2) { rep.push(mine, m2, F.fr); });
@@ -420,7 +440,7 @@ __device__ __forceinline__ void pbSweepC(const PbDevParams &P, PR prIn, VL velIn
 #endif
       }
     }
-    if (!ASUM) rep.flush(F.fr);
+    if (REPL) rep.flush(F.fr);
     return;
   }
   if (FLAT && NB == 2) {

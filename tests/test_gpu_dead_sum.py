@@ -149,6 +149,29 @@ def test_constrained_contraction_keeps_both_sums(pb, orc):
     check(osim, gsim, 1, "constrained contraction")
 
 
+@pytest.mark.parametrize("ndead", [0, -1])
+@pytest.mark.parametrize("attraction", [0.0, 3e-12, 2e-9, 5e-7, 1.0e-6, 4e-4])
+def test_both_sums_with_weak_attraction_constants(pb, orc, attraction, ndead):
+    """Round 5: the both-sums throughput form roots |F_attr| from one v_rsq_f32 + one Newton step without a per-trip
+    domain check, which is exact for 0 and for [2^-96, FLT_MAX); pbAttractionMagnitudeSafe admits a batch to that path
+    only when every attraction constant a pair can see is 0 or >= 2^-20 (9.5e-7).  Constants below that (and above
+    2^-40, so that the rest of the fast forms stay on), exactly at the edge, at the reference's default and 0: every
+    array incl. absForce_a bit-identical to the oracle, with the payload's factors squaring the constant down."""
+    n = 5000
+    P = orc.default_params(nCells=n, nDead=ndead, seed=21, phase_std=0.0, max_time=1e9, light_x=-3.0, light_y=0.5,
+                           attraction=attraction, attractionFactor=0.25, massFactor=2.0)
+    osim, gsim = build(pb, orc, P, blob_state(n, 31), 1)
+    cfg = gsim.config()
+    assert cfg["lanes_per_bot"] == 1 and cfg["attraction_sums"] == 1 and cfg["dead_sum_form"] == 0
+    step = 0
+    for upto in (1, 2, 30):
+        osim.run(upto - step)
+        assert gsim.step(upto - step) == upto - step
+        step = upto
+        check(osim, gsim, 1, f"attraction {attraction}, step {upto}")
+    assert np.isfinite(osim.get("absForce_a")).all()   # (never all zero: the 2.5 N band does not depend on the constant)
+
+
 def test_64bit_offset_form(pb, orc, monkeypatch):
     """The 64-bit-offset throughput sweep (batches of 2^28 bots and more) has the dead-sum form too;
     the debug knob runs it on a small batch."""
