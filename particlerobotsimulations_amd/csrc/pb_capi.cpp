@@ -507,15 +507,18 @@ void describeResources(pbHostResources &r, int wanted) {
   r.local_world_size = localWorldSize();
   int share = std::max(1, r.usable_cpus / r.local_world_size);
   const char *why = "usable cores / ranks of the node";
+  bool automatic = true;  // the share is the rule's, not a number somebody asked for
   if (const char *v = getenv("PB_HOST_THREADS")) {
     if (atoi(v) > 0) {
       share = atoi(v);
       why = "PB_HOST_THREADS";
+      automatic = false;
     }
   }
   if (wanted > 0) {
     share = wanted;
     why = "host_threads argument";
+    automatic = false;
   }
   r.host_threads = std::max(1, std::min(share, 128));
   r.device = -1;
@@ -538,7 +541,6 @@ void describeResources(pbHostResources &r, int wanted) {
   const char *pinNote = r.pin_producers ? "pinned to the GPU's NUMA node" : "not pinned (no NUMA node reported for the device)";
   if (pin && pin[0] == '0' && r.numa_node >= 0) pinNote = "not pinned (PB_PIN_PRODUCERS=0)";
   if (r.pin_producers && r.host_threads > r.numa_cpus) {
-    const bool automatic = strcmp(why, "usable cores / ranks of the node") == 0;
     if (automatic && r.local_world_size > 1) {
       r.host_threads = r.numa_cpus;
       pinNote = "pinned to the GPU's NUMA node, share clamped to its cores";
