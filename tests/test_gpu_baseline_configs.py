@@ -63,6 +63,10 @@ def test_bench_headline_workload_matches_oracle(orc):
         assert (a.x, a.y) == (b.x, b.y), name
     gsim = bench.make_sim(pb, n, bench.LATTICE_PITCH, seed=1)
     assert gsim.config()["force_variant"] == 2 and gsim.config()["lanes_per_bot"] == 1
+    # ... and the line's `both_sums` leg, the kernel `roofline.frac` is priced on (everything collideD writes)
+    gboth = bench.make_sim(pb, n, bench.LATTICE_PITCH, seed=1)
+    gboth.set_force_sums(1)
+    assert gboth.config()["attraction_sums"] == 1 and gboth.config()["dead_sum_form"] == 0
     orc.lib().orc_set_num_threads(orc.usable_cpus())
     osim = orc.Sim(P, reset=True, hex=True)
     osim.set("pos", bench.square_lattice(n, bench.LATTICE_PITCH))
@@ -75,11 +79,18 @@ def test_bench_headline_workload_matches_oracle(orc):
         for key in STATE_KEYS:
             assert_bit_equal(st[key], osim.get(key), f"bench workload, step {done}: {key}")
         assert gsim.time == osim.time
+        gboth.step(upto - gboth.stats()["steps"])
+        sb = gboth.get_state()
+        for key in tuple(STATE_KEYS) + ("absForce_a",):
+            if sb[key] is not None:
+                assert_bit_equal(sb[key], osim.get(key), f"bench workload with both sums, step {done}: {key}")
+        assert sb["absForce_a"] is not None
     # the lattice is in contact everywhere: a dense, jammed workload (not a dilute gas)
     assert (st["absForce_r"] > 0).mean() > 0.99
     s = gsim.stats()
     assert s["resorts"] == 1 and s["fused_launches"] >= 29
     gsim.close()
+    gboth.close()
     osim.close()
 
 
