@@ -26,6 +26,10 @@ def test_headline_and_stream_kernels_keep_eight_waves_per_simd(regs):
     assert vgpr <= 64 and scratch == 0 and lds == 9216, (vgpr, sgpr, lds, scratch)
     vgpr, sgpr, lds, scratch = regs["k_force_stream<false, false>"]
     assert vgpr <= 64 and scratch == 0 and lds <= 12288, (vgpr, sgpr, lds, scratch)
+    # the form roofline.frac is priced on since round 5 (both magnitude sums; contact magnitudes parked in LDS like the
+    # default form's)
+    vgpr, sgpr, lds, scratch = regs["k_force<false, true, 1, 1, false, true>"]
+    assert vgpr <= 64 and scratch == 0 and lds == 9216, (vgpr, sgpr, lds, scratch)
 
 
 def test_no_force_kernel_spills_and_all_forms_are_there(regs):
