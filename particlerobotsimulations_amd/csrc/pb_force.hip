@@ -43,12 +43,25 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
                                                 float *__restrict__ absA, float *__restrict__ absR,
                                                 const uint32_t *__restrict__ orig,
                                                 const uint32_t *__restrict__ cellSAll, uint32_t n, float dt,
-                                                float timeNext, int doRadiusNext, uint32_t perXcd, int fuse, int fastOk) {
-  const PbDevParams &P = params[blockIdx.y];
+                                                float timeNext, int doRadiusNext, uint32_t perXcd, int fuse, int fastOk,
+                                                uint32_t memberTiles, uint32_t nsims) {
+  // memberTiles != 0 (round 5: batches of >= 8 small simulations, 1-D grid): workgroups b, b+8, b+16, ... share an XCD
+  // (round-robin dispatch) and every XCD has its own L2: ALL tiles of a member go to one XCD, so that the neighbour
+  // reads of a member's tiles -- the same few KB -- meet in one L2 instead of missing in eight.  BASELINE configs[3] on
+  // one GPU: 32 + 32 members 7.75 -> 7.31 us per step, 64 + 64 members 10.22 -> 9.40, 8 + 8 unchanged
+  // (tools/experiments/ab_xcd_members.sh); the results do not depend on the mapping.
+  uint32_t member = blockIdx.y, tileX = blockIdx.x;
+  if (memberTiles) {
+    const uint32_t r = blockIdx.x >> 3;
+    member = (r / memberTiles) * 8u + (blockIdx.x & 7u);
+    tileX = r % memberTiles;
+    if (member >= nsims) return;
+  }
+  const PbDevParams &P = params[member];
   // XCD-aware tile order (large simulations): workgroups b, b+8, b+16, ... share an XCD
   // (round-robin dispatch); give each XCD one contiguous eighth of the tiles (gridDim.x = 8*perXcd).
   // perXcd == 0: plain order (small simulations, a handful of tiles each).
-  const uint32_t tile = perXcd ? (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t tile = perXcd ? (tileX & 7u) * perXcd + (tileX >> 3) : tileX;
   const uint32_t l = tile * (TILE / L) + threadIdx.x / L;  // all L lanes of a group share the bot
   const uint32_t sub = threadIdx.x % L;
 #ifdef PB_TIMELINE
@@ -56,8 +69,8 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
   PB_TL_STAMP(0);
 #endif
   if (l >= n) return;
-  const uint32_t s = blockIdx.y * n + l;  // global slot; the cell table holds global slots too
-  const uint32_t *__restrict__ cellS = cellSAll + (size_t)blockIdx.y * (P.numCells + 1u);
+  const uint32_t s = member * n + l;  // global slot; the cell table holds global slots too
+  const uint32_t *__restrict__ cellS = cellSAll + (size_t)member * (P.numCells + 1u);
 
   const float4 me = prIn[s];
   float2 v = velIn[s];
@@ -111,7 +124,12 @@ void launchForceT(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int 
   const uint32_t tiles = cdiv(S->n, TILE / L);
   // XCD-aware order only pays when a simulation spans many tiles
   const uint32_t perXcd = (L == 1 && tiles >= 64u) ? cdiv(tiles, 8u) : 0u;
-  const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
+  dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
+  uint32_t memberTiles = 0u;
+  if (S->xcdMembers && !perXcd && S->nsims >= 8u) {
+    memberTiles = tiles;
+    grid = dim3(cdiv(S->nsims, 8u) * 8u * tiles, 1u);
+  }
   constexpr int NB = (FLAT && L == 1 && !BIG && ASUM) ? PB_THROUGHPUT_NB : 1;
   // (the both-sums throughput form roots its attraction magnitudes without a domain check: pbAttractionMagnitudeSafe)
   const bool magNeeded = ASUM && FLAT && L == 1 && PB_ASUM_XY;
@@ -119,7 +137,7 @@ void launchForceT(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int 
   // (debugLdsBytes: an occupancy experiment -- unused dynamic LDS that only limits workgroups per CU)
   hipLaunchKernelGGL((k_force<PAYLOAD, FLAT, L, NB, BIG, ASUM>), grid, dim3(TILE), S->debugLdsBytes, S->stream, S->dP,
                      S->pr[c], S->vel[c], S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c],
-                     S->orig[c], S->cellS, S->n, dt, tNext, doRadiusNext, perXcd, (int)fuse, fastOk);
+                     S->orig[c], S->cellS, S->n, dt, tNext, doRadiusNext, perXcd, (int)fuse, fastOk, memberTiles, S->nsims);
 }
 
 // ---- the forms table ---------------------------------------------------------------------------
