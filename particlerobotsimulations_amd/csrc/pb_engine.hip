@@ -736,6 +736,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     if (const char *v = getenv("PB_DEBUG_LDS_BYTES")) S->debugLdsBytes = (unsigned)std::min(atol(v), 65536L);
     if (const char *v = getenv("PB_DEBUG_FORCE_BIG")) S->wideOffsets = atoi(v) != 0;
     if (const char *v = getenv("PB_XCD_MEMBERS")) S->xcdMembers = atoi(v) != 0;
+    if (const char *v = getenv("PB_XCD_TILES_ALL")) S->xcdTilesAll = atoi(v) != 0;
     if (rc != PB_OK) {
       pbLastError() = "pbSimCreateBatch: PB_FORCE_VARIANT / PB_LANES_PER_BOT / PB_RESIDENT out of range";
       delete S;

@@ -75,6 +75,7 @@ struct pbSim {
   bool resortEveryStep = false;
   bool payload = false, fastOk = false;
   bool xcdMembers = true;   // batches of >= 8 small members: all tiles of a member on one XCD (PB_XCD_MEMBERS=0 under PB_ALLOW_ENV_OVERRIDES: the plain (tile, member) grid, for A/B)
+  bool xcdTilesAll = true;   // the XCD-contiguous tile order for the multi-lane forms too (PB_XCD_TILES_ALL=0 under PB_ALLOW_ENV_OVERRIDES: only for one bot per lane, as rounds 1-4)
   bool magOk = false;   // every member passes pbAttractionMagnitudeSafe (fast path of the both-sums throughput form)
   int variant = 2;  // force kernel: 0 reference-shaped branches, 1 branch-free, 2 (default) + fast exact math
   int resident = 0;     // 0 automatic, 1 never, 2 whenever the simulation fits one workgroup (n <= 1024)

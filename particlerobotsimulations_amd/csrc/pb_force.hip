@@ -122,8 +122,9 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
 template <bool PAYLOAD, bool FLAT, int L, bool BIG, bool ASUM>
 void launchForceT(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext) {
   const uint32_t tiles = cdiv(S->n, TILE / L);
-  // XCD-aware order only pays when a simulation spans many tiles
-  const uint32_t perXcd = (L == 1 && tiles >= 64u) ? cdiv(tiles, 8u) : 0u;
+  // XCD-aware order only pays when a simulation spans many tiles.  (Round 5: for the multi-lane forms too -- one
+  // simulation of 4 000 ... 10^5 bots steps 1-4 % faster in its automatic form, profiles/r5_xcd_tiles_all.txt.)
+  const uint32_t perXcd = ((L == 1 || S->xcdTilesAll) && tiles >= 64u) ? cdiv(tiles, 8u) : 0u;
   dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
   uint32_t memberTiles = 0u;
   if (S->xcdMembers && !perXcd && S->nsims >= 8u) {
