@@ -403,6 +403,45 @@ def _ensemble_batch_vs_oracles(pb, orc, resident, min_distance_mode):
     assert (s["resident_launches"] > 0) == (resident == 2)
 
 
+@pytest.mark.parametrize("nsims,bots,lanes", [(8, 300, 0), (9, 300, 8), (17, 130, 64), (13, 700, 1), (24, 201, 16),
+                                              (5, 300, 8)])
+def test_one_xcd_per_member_grid_with_ragged_batches(pb, orc, nsims, bots, lanes, monkeypatch):
+    """Round 5: batches of >= 8 small members launch the per-step force kernel on a 1-D grid decoded as
+    member = (b / 8 / tiles) * 8 + b mod 8 (all tiles of a member on one XCD).  Member counts that are not a multiple of
+    eight (the last group is padded with workgroups that exit), one tile per member, the one-bot-per-lane form on small
+    members, fewer than eight members (plain grid): every member bit-identical to its own oracle run, and to the same
+    batch stepped with the plain (tile, member) grid."""
+    members, keep, osims = [], [], []
+    for k in range(nsims):
+        P = orc.default_params(nCells=bots, nDead=0, seed=300 + k, light_x=-4.0 + 0.3 * k, light_y=0.2 * k, phase_std=0.4,
+                               max_time=1e9)
+        sp, ka = simparams_from_orc(P)
+        members.append(sp)
+        keep.append(ka)
+        osims.append(orc.Sim(P))
+    runs = {}
+    for grid in ("xcd", "plain"):
+        monkeypatch.setenv("PB_ALLOW_ENV_OVERRIDES", "1")
+        monkeypatch.setenv("PB_XCD_MEMBERS", "1" if grid == "xcd" else "0")
+        ens = pb.Ensemble(members, keepalive=keep)
+        ens.set_resident(1)
+        ens.set_lanes_per_bot(lanes)
+        for k, osim in enumerate(osims):
+            ens.set_state_of(k, pos=osim.get("pos"), vel=osim.get("vel"), rad=osim.get("rad"), phase=osim.get("phase"),
+                             dead=osim.get("dead"))
+        assert ens.step(60, sort_interval=0.25) == 60
+        runs[grid] = [ens.get_state_of(k) for k in range(nsims)]
+        assert ens.stats()["resident_launches"] == 0 and ens.stats()["resorts"] >= 2
+        ens.close()
+    for osim in osims:
+        osim.run(60, sort_interval=0.25)
+    for k, osim in enumerate(osims):
+        for key in STATE_KEYS:
+            assert_bit_equal(runs["xcd"][k][key], osim.get(key), f"member {k}: {key}")
+            assert_bit_equal(runs["plain"][k][key], runs["xcd"][k][key], f"member {k}, plain grid: {key}")
+        osim.close()
+
+
 def test_ensemble_rejects_mismatched_members(pb, orc):
     a, ka = simparams_from_orc(orc.default_params(nCells=100, nDead=0, seed=1))
     b, kb = simparams_from_orc(orc.default_params(nCells=101, nDead=0, seed=2))
