@@ -154,7 +154,7 @@ static inline bool pbFastMathAllowed(const PbDevParams &d) {
 // Precondition of the both-sums throughput form's attraction magnitude (pbPairEvalXY<FAST, true>): the root of
 // |term|^2 comes from pbRootNewton, exact for 0 and for [2^-96, FLT_MAX).  A non-contact term is the 2.5 N band or
 // A * n / gap^2 with gap^2 < 2^27 (above) and max(|nx|, |ny|) >= 2^-0.5, so |term|^2 >= A^2 * 2^-55: inside the domain
-// when every attraction constant a pair can see is 0 or >= 2^-20 (the reference's default is 4e-4 = 2^-11.3).  A batch
+// when every attraction constant a pair can see is 0 or >= 2^-20 (the reference's default is 4.8e-5 = 2^-14.4).  A batch
 // that fails it runs that form's plain IEEE path.
 static inline bool pbAttractionMagnitudeSafe(const PbDevParams &d) {
   auto okA = [](float a) { return a == 0.0f || a >= 0x1p-20f; };
