@@ -148,3 +148,13 @@ def test_arena_line_through_rccl_with_one_rank_and_gpus_flag_is_checked():
                          capture_output=True, text=True, timeout=60, cwd=ROOT,
                          env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr
+
+
+def test_force_sums_flag_profiles_the_both_sums_kernel_as_the_arena():
+    """`bench.py --force-sums 1` (what tools/profile.sh runs for profiles/r5_both_sums.*): the arena itself keeps both
+    magnitude sums, so that kernel is the one under the profiler; the line says it is not the headline."""
+    d = _bench("--bots", "100000", "--steps", "40", "--warmup", "10", "--force-sums", "1", "--no-cpu-baseline",
+               "--no-survey-literal", "--no-streamlined", "--no-large-arena", "--no-clock", "--no-blob", "--no-ensemble-leg",
+               "--no-both-sums", "--no-host-round-trip")
+    assert d["headline"] is False and d["config"]["attraction_sums"] == 1 and d["config"]["dead_sum_form"] == 0
+    assert d["value"] > 0 and "both_sums" not in d and "collideD" not in d["roofline"]["frac_is"]
