@@ -38,13 +38,17 @@ namespace {
 template <bool PAYLOAD, bool FLAT, int L, int NB, bool BIG, bool ASUM>
 __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) void k_force(const PbDevParams *__restrict__ params,
                                                 const float4 *__restrict__ prIn, const float2 *__restrict__ velIn,
+                                                const uint32_t *__restrict__ cellSAll, float *__restrict__ absR,
+                                                uint32_t n, uint32_t perXcd, uint32_t memberTiles, uint32_t nsims,
+                                                float dt, int fastOk,
+                                                // -- the first 16 dwords arrive in SGPRs with the wave (kernarg preload):
+                                                // everything the tile decode, the own-state loads and the sweep need is
+                                                // above this line, so a launch does not start with a scalar round trip
+                                                // for its arguments; what follows is first used after the sweep --
                                                 float4 *__restrict__ prOut, float2 *__restrict__ velOut,
                                                 const float *__restrict__ phase, const int *__restrict__ dead,
-                                                float *__restrict__ absA, float *__restrict__ absR,
-                                                const uint32_t *__restrict__ orig,
-                                                const uint32_t *__restrict__ cellSAll, uint32_t n, float dt,
-                                                float timeNext, int doRadiusNext, uint32_t perXcd, int fuse, int fastOk,
-                                                uint32_t memberTiles, uint32_t nsims) {
+                                                float *__restrict__ absA, const uint32_t *__restrict__ orig,
+                                                float timeNext, int doRadiusNext, int fuse) {
   // memberTiles != 0 (round 5: batches of >= 8 small simulations, 1-D grid): workgroups b, b+8, b+16, ... share an XCD
   // (round-robin dispatch) and every XCD has its own L2: ALL tiles of a member go to one XCD, so that the neighbour
   // reads of a member's tiles -- the same few KB -- meet in one L2 instead of missing in eight.  BASELINE configs[3] on
@@ -137,8 +141,8 @@ void launchForceT(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int 
   const int fastOk = (S->variant >= 2 && S->fastOk && (!magNeeded || S->magOk)) ? 1 : 0;
   // (debugLdsBytes: an occupancy experiment -- unused dynamic LDS that only limits workgroups per CU)
   hipLaunchKernelGGL((k_force<PAYLOAD, FLAT, L, NB, BIG, ASUM>), grid, dim3(TILE), S->debugLdsBytes, S->stream, S->dP,
-                     S->pr[c], S->vel[c], S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c],
-                     S->orig[c], S->cellS, S->n, dt, tNext, doRadiusNext, perXcd, (int)fuse, fastOk, memberTiles, S->nsims);
+                     S->pr[c], S->vel[c], S->cellS, S->absR[c], S->n, perXcd, memberTiles, S->nsims, dt, fastOk, S->pr[o],
+                     S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->orig[c], tNext, doRadiusNext, (int)fuse);
 }
 
 // ---- the forms table ---------------------------------------------------------------------------
