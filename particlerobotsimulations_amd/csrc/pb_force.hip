@@ -41,10 +41,11 @@ __global__ __launch_bounds__(TILE, (NB == 2 ? PB_NB2_WAVES : PB_FORCE_WAVES)) vo
                                                 const uint32_t *__restrict__ cellSAll, float *__restrict__ absR,
                                                 uint32_t n, uint32_t perXcd, uint32_t memberTiles, uint32_t nsims,
                                                 float dt, int fastOk,
-                                                // -- the first 16 dwords arrive in SGPRs with the wave (kernarg preload):
-                                                // everything the tile decode, the own-state loads and the sweep need is
-                                                // above this line, so a launch does not start with a scalar round trip
-                                                // for its arguments; what follows is first used after the sweep --
+                                                // -- up to here (14 dwords: 16 user SGPRs, two of them the kernarg
+                                                // pointer) the arguments arrive in SGPRs with the wave (kernarg preload):
+                                                // the tile decode and the own-state loads need nothing else, so a launch
+                                                // does not start with a scalar round trip for its arguments (fastOk in
+                                                // there instead of absR: measured equal); what follows is used later --
                                                 float4 *__restrict__ prOut, float2 *__restrict__ velOut,
                                                 const float *__restrict__ phase, const int *__restrict__ dead,
                                                 float *__restrict__ absA, const uint32_t *__restrict__ orig,
