@@ -557,6 +557,9 @@ def valu_roofline(tr, n, avg_launch_us, clock_mhz):
     for k in ("wave_cycle_split", "valu_lane_utilisation"):
         if k in tr:
             out[k] = tr[k]
+    # the same figure as roofline.valu_frac_of_datasheet (instructions x 64 lanes / time / 78.6e12), under the name the
+    # round-4 review used
+    out["frac_of_datasheet"] = valu_of_datasheet(tr, n, avg_launch_us)
     return out
 
 
