@@ -16,6 +16,7 @@
 #define PARTICLEBOT_H
 
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #include "particlebot_hip.h"
@@ -156,6 +157,24 @@ class Particlebot {
   void getHostRngState(int out[36]) const { rng.getState(out); }
   void setHostRngState(const int in[36]) { rng.setState(in); }
   void restoreHostMirrors(const float *pos, const float *vel, const float *rad, const float *phase, const int *dead);
+  /* Extension (ensemble pipeline: members of a sweep that share seed and geometry are placed ONCE).  placementKey():
+   * every input reset() reads -- the seed of the private generator, nCells, min/max_radius, the payload flag
+   * (nDead == -1) and radFactor with it, config and the pb_placement extensions, the lattice pitch, Nx as given, and
+   * the grid the placement bins into (gridSize, worldOrigin, cellSize).  nDead >= 0 is NOT part of it: the reference's
+   * placement reads nDead only for the payload (particlebot.cpp:731, 786).  Two instances with equal keys place
+   * identically, so one may take the other's result: exportPlacement() right after reset() captures positions, radii,
+   * phases, dead flags, Nx and the generator's state AFTER the placement draws (the dead draw continues that stream,
+   * particlebot.cpp:178-194); importPlacement() installs it in place of reset().  HostOnly engines. */
+  struct Placement {
+    std::vector<float> pos, rad, phase;
+    std::vector<int> dead;
+    int rng[36];
+    unsigned configX, configY, Nx;
+  };
+  std::string placementKey() const { return placementKeyOf(params, hexSpacing, squareLattice, fastBlob); }
+  static std::string placementKeyOf(const SimParams &params, float hexSpacing, bool squareLattice, bool fastBlob);
+  void exportPlacement(Placement &out) const;
+  bool importPlacement(const Placement &in);
 
  protected:
   void _initialize();

@@ -66,6 +66,9 @@ typedef struct pbEnsembleTimings {
   double placement_thread_wall_s; /* wall seconds the producers spent building members (sum over threads): exceeds
                                placement_cpu_s when the threads did not get a core each (oversubscription, quota) */
   int lanes;                /* sub-batches stepped at the same time; placement_wait_s, upload_s and device_s are per lane */
+  int placements_run;       /* placements actually computed (Particlebot::reset): one per DISTINCT blob of this pipeline */
+  int placements_shared;    /* members that took a copy of another member's placement (equal placement keys: same seed,
+                               size, radii, grid -- e.g. the points of an nDead sweep under one seed) */
 } pbEnsembleTimings;
 void *pbEnsemblePipelineCreate(const char *cfg_path, const char *common_overrides, const char **member_overrides,
                                int nmembers, int sub_batch, int host_threads, int keep_final_states);
@@ -100,6 +103,9 @@ int pbEnsemblePipelineSetCsvDir(void *pipeline, const char *dir, const int *ids)
  * never more than that many bots whatever the size of the pool. */
 int pbEnsemblePipelineAutoSubBatch(unsigned bots_per_member, int producers);
 unsigned pbEnsemblePipelineNumBots(void *pipeline);
+/* Placements computed / members that took a copy of another member's placement, so far (pbEnsembleTimings carries the
+ * same two after a Run; this getter also serves the device-less DryRun). */
+void pbEnsemblePipelinePlacementCounts(void *pipeline, int *run, int *shared);
 int pbEnsemblePipelineGetState(void *pipeline, int member, float *pos, float *vel, float *rad);
 /* The consumer side without a device (CPU tests): takes the sub-batches in order as Run does, records a checksum
  * of every member's placed state instead of stepping it, dwells dwell_ms per sub-batch; *max_ahead = the most

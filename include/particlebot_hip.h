@@ -318,6 +318,22 @@ typedef struct pbForceForm {
 int pbForceFormCount(void);
 int pbForceFormGet(int index, pbForceForm *form);
 int pbSimSelectForceForm(pbSim *sim, int index);
+/* The per-step force kernel this batch launches next, named as rocprofv3 names it (template arguments and
+ * argument types, no "void", no namespace): "k_force<false, true, 1, 1, false, true>(PbDevParams const*, ...)".
+ * bench.py matches it against the signature recorded in profiles/latest_traffic*.json before quoting that
+ * profile's counters.  PB_ERR_ARG when `cap` is too small. */
+int pbSimForceKernelName(pbSim *sim, char *buf, size_t cap);
+/* The same for row `index` of the forms table (no device needed). */
+int pbForceFormKernelName(int index, int payload, char *buf, size_t cap);
+
+/* How the streamlined kernel (force variant 3) visits a bot's 25-cell stencil: 0 row by row (the wave runs the longest
+ * row of its 64 lanes, five times), 1 flattened (every lane walks its own five ranges back to back; the wave runs its
+ * longest list), -1 (default) chosen for the batch at every re-sort from the trip counts of both (flattened when it
+ * saves >= 7 % of the trips: random blobs -- BASELINE configs[4] steps 7-9 % faster --, not the bench lattice).  Same
+ * candidates in the same order: the results do not depend on it, bit for bit.  No effect on the exact kernels.
+ * pbSimGetStreamWalkTrips: the two trip counts of the last choice (0, 0 before one was made). */
+int pbSimSetStreamWalk(pbSim *sim, int mode);
+int pbSimGetStreamWalkTrips(pbSim *sim, unsigned long long *row_by_row, unsigned long long *flattened);
 
 typedef struct pbSimConfig {
   int force_variant;
@@ -330,6 +346,7 @@ typedef struct pbSimConfig {
   int offsets64; /* 1: the throughput sweep runs with 64-bit byte offsets (batches of 2^28 bots and more) */
   int attraction_sums; /* 1: absForce_a is maintained (pbSimSetForceSums) */
   int dead_sum_form;   /* 1: the force kernel that runs is a form without Sum|F_attr| */
+  int stream_walk;     /* 1: the streamlined kernel runs and walks its stencil flattened (pbSimSetStreamWalk) */
 } pbSimConfig;
 int pbSimGetConfig(pbSim *sim, pbSimConfig *cfg);
 

@@ -62,6 +62,13 @@ def force_forms():
     return out
 
 
+def force_form_kernel_name(index, payload=0):
+    """Row `index` of the forms table as rocprofv3 names its kernel (pbForceFormKernelName; no device needed)."""
+    buf = C.create_string_buffer(2048)
+    _capi.check(_capi.lib().pbForceFormKernelName(int(index), int(payload), buf, len(buf)), "pbForceFormKernelName")
+    return buf.value.decode()
+
+
 def library_paths():
     return {"hip": _capi.HIP_SO, "host": _capi.HOST_SO}
 
@@ -296,10 +303,27 @@ class Sim:
         _capi.check(_capi.lib().pbSimGetConfig(self._h, C.byref(c)))
         return {k: int(getattr(c, k)) for k, _ in pbSimConfig._fields_}
 
+    def force_kernel_name(self):
+        """The per-step force kernel the next step() launches, as rocprofv3 names it (pbSimForceKernelName)."""
+        buf = C.create_string_buffer(2048)
+        _capi.check(_capi.lib().pbSimForceKernelName(self._h, buf, len(buf)), "pbSimForceKernelName")
+        return buf.value.decode()
+
     def set_force_variant(self, variant):
         """0/1/2: exact kernels (bit-identical to the oracle; 2 is the default).  3: streamlined
         arithmetic, opt-in, not bit-identical (include/particlebot_hip.h)."""
         _capi.check(_capi.lib().pbSimSetForceVariant(self._h, int(variant)))
+
+    def set_stream_walk(self, mode):
+        """-1 (default): the streamlined kernel's neighbour walk is chosen at every re-sort; 0 row by row; 1 flattened
+        (pbSimSetStreamWalk; bit-identical either way)."""
+        _capi.check(_capi.lib().pbSimSetStreamWalk(self._h, int(mode)), "pbSimSetStreamWalk")
+
+    def stream_walk_trips(self):
+        """(row-by-row, flattened) trips per wave summed over the batch, from the last automatic choice."""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        _capi.check(_capi.lib().pbSimGetStreamWalkTrips(self._h, C.byref(a), C.byref(b)), "pbSimGetStreamWalkTrips")
+        return a.value, b.value
 
     def set_force_sums(self, mode):
         """0 (default): absForce_a only when a member reads it (constrained_contraction); otherwise it

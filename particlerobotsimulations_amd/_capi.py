@@ -74,7 +74,7 @@ class pbSimStats(C.Structure):
 class pbSimConfig(C.Structure):
     _fields_ = [("force_variant", C.c_int), ("force_kind", C.c_int), ("lanes_per_bot", C.c_int),
                 ("resident", C.c_int), ("fast_math_ok", C.c_int), ("payload", C.c_int), ("rng", C.c_int), ("offsets64", C.c_int),
-                ("attraction_sums", C.c_int), ("dead_sum_form", C.c_int)]
+                ("attraction_sums", C.c_int), ("dead_sum_form", C.c_int), ("stream_walk", C.c_int)]
 
 
 class pbForceForm(C.Structure):
@@ -151,9 +151,13 @@ SYMBOLS = {
     "pbSimSetResident": (_I, [_VP, _I]),
     "pbSimGetConfig": (_I, [_VP, C.POINTER(pbSimConfig)]),
     "pbSimSetForceSums": (_I, [_VP, _I]),
+    "pbSimSetStreamWalk": (_I, [_VP, _I]),
+    "pbSimGetStreamWalkTrips": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "pbForceFormCount": (_I, []),
     "pbForceFormGet": (_I, [_I, C.POINTER(pbForceForm)]),
     "pbSimSelectForceForm": (_I, [_VP, _I]),
+    "pbSimForceKernelName": (_I, [_VP, C.c_char_p, C.c_size_t]),
+    "pbForceFormKernelName": (_I, [_I, _I, C.c_char_p, C.c_size_t]),
     "pbSimSetRng": (_I, [_VP, _I]),
     "pbSimGetRngStatesOf": (_I, [_VP, _U, _VP]),
     "pbSetRngKind": (_I, [_I]),

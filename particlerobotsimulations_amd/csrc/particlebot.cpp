@@ -1094,6 +1094,47 @@ void Particlebot::reset() {
   }
 }
 
+// ---- one placement for several members (extension; include/particlebot.h) --------------------------
+std::string Particlebot::placementKeyOf(const SimParams &params, float hexSpacing, bool squareLattice, bool fastBlob) {
+  // everything reset() and the placement routines above read (grep `params.` / `rng` / the setters in this file)
+  struct Key {
+    unsigned seed, nCells, config, gridX, gridY, Nx;
+    int payload, square, fast;
+    float minRadius, maxRadius, radFactor, originX, originY, cellX, cellY, pitch;
+  } k;
+  memset(&k, 0, sizeof k);
+  k.seed = params.seed, k.nCells = params.nCells, k.config = (unsigned)params.config;
+  k.gridX = params.gridSize.x, k.gridY = params.gridSize.y, k.Nx = params.Nx;
+  k.payload = params.nDead == -1 ? 1 : 0, k.square = squareLattice ? 1 : 0, k.fast = fastBlob ? 1 : 0;
+  k.minRadius = params.min_radius, k.maxRadius = params.max_radius;
+  k.radFactor = k.payload ? params.radFactor : 0.0f;
+  k.originX = params.worldOrigin.x, k.originY = params.worldOrigin.y;
+  k.cellX = params.cellSize.x, k.cellY = params.cellSize.y, k.pitch = hexSpacing;
+  return std::string((const char *)&k, sizeof k);
+}
+
+void Particlebot::exportPlacement(Placement &out) const {
+  out.pos = hPosV, out.rad = hRadV, out.phase = hPhaseV, out.dead = hDeadV;
+  rng.getState(out.rng);
+  out.configX = particlebotConfigSize.x, out.configY = particlebotConfigSize.y, out.Nx = params.Nx;
+}
+
+bool Particlebot::importPlacement(const Placement &in) {
+  if (engineKind != Engine::HostOnly || in.pos.size() != hPosV.size() || in.rad.size() != hRadV.size() ||
+      in.phase.size() != hPhaseV.size() || in.dead.size() != hDeadV.size())
+    return false;
+  time = 0;
+  std::fill(hVelV.begin(), hVelV.end(), 0.0f);
+  std::copy(in.pos.begin(), in.pos.end(), hPosV.begin());
+  std::copy(in.rad.begin(), in.rad.end(), hRadV.begin());
+  std::copy(in.phase.begin(), in.phase.end(), hPhaseV.begin());
+  std::copy(in.dead.begin(), in.dead.end(), hDeadV.begin());
+  rng.setState(in.rng);
+  particlebotConfigSize.x = in.configX, particlebotConfigSize.y = in.configY;
+  params.Nx = in.Nx;
+  return true;
+}
+
 // ---- exact checkpoints (extension) -----------------------------------------
 
 namespace {

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <climits>
 #include <condition_variable>
+#include <map>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -364,10 +365,18 @@ bool configureMember(Member &m, const char *cfg_path, const char *common_overrid
   return true;
 }
 
-bool buildMember(Member &m, const char *cfg_path, const char *common_overrides, const char *own_overrides) {
+// `shared`: a placement another member with the same Particlebot::placementKey() produced (installed instead of
+// reset(): same positions, same generator state after the placement draws); `out`: capture this member's own.
+bool buildMember(Member &m, const char *cfg_path, const char *common_overrides, const char *own_overrides,
+                 const Particlebot::Placement *shared = nullptr, Particlebot::Placement *out = nullptr) {
   if (!configureMember(m, cfg_path, common_overrides, own_overrides)) return false;
   Particlebot *bot = m.bot;
-  bot->reset();
+  if (shared) {
+    if (!bot->importPlacement(*shared)) return false;
+  } else {
+    bot->reset();
+    if (out) bot->exportPlacement(*out);
+  }
   bot->setHostTime(0.0f);
   if (bot->deadDrawDue(m.cfg->timestep)) {  // particlebot.cpp:178: drawn at the top of the first update()
     (void)bot->drawDeadBotsNow();
@@ -795,6 +804,19 @@ bool uploadRestored(Ensemble *e, float *out, int max_rows) {
   return true;
 }
 
+// How many summary rows a run from t = 0 writes: the clock and the gate of runSteps below (fp32 t = t + dt; a row
+// whenever !(t - di * floorf(t / di) > 0.01f), the last one at the first t > max_time), for at most max_steps steps.
+// Stops counting at `limit` + 1: callers only ask "does it fit".
+long rowsNeeded(float dt, float di, float max_time, long max_steps, long limit) {
+  long rows = 0, steps = 0;
+  for (float t = 0.0f;; t = t + dt, steps++) {
+    if (!(t - di * floorf(t / di) > 0.01f) && ++rows > limit) break;
+    if (t > max_time || steps >= max_steps) break;
+    if (t + dt == t) return limit + 1;  // the fp32 clock has stopped short of max_time: rows without end
+  }
+  return rows;
+}
+
 // Runs every member of the batch for up to max_steps timesteps (or to max_time, whichever comes first); can be
 // called again to continue.  Row r of member k goes to out[(k * max_rows + r) * 4 ..]: (time, COMx, COMy, distance
 // of the COM to the light), one row whenever a dump row would be due (particlebot.cpp:309).
@@ -813,9 +835,16 @@ long runSteps(Ensemble *e, long max_steps, float *out, int max_rows, int *rows) 
     const bool rowDue = !(t - di * floorf(t / di) > 0.01f) && !(e->haveRow && e->rowTime == t);
     if (rowDue && !e->csvDir.empty() && (!out || nrows >= max_rows)) {
       // the member CSVs are documented as byte for byte the reference's: never a silently shortened file
+      // (pbEnsemblePipelineRun refuses such a run before its first step; this is the stepwise API's guard)
       fprintf(stderr, "pbEnsemble: a CSV row is due at t = %g but the row buffer holds %d rows (max_rows %d): "
               "%s/member_*.csv would stop here; raise max_rows or the dump interval\n",
               (double)t, out ? nrows : 0, out ? max_rows : 0, e->csvDir.c_str());
+      return -1;
+    }
+    if (rowDue && out && nrows >= max_rows) {
+      // (the same for the summary rows themselves: a caller who passes a buffer gets every row or an error)
+      fprintf(stderr, "pbEnsemble: a summary row is due at t = %g but the row buffer is full (max_rows %d); raise max_rows "
+              "or the dump interval, or pass no buffer\n", (double)t, max_rows);
       return -1;
     }
     if (out && rowDue && nrows < max_rows) {
@@ -946,6 +975,123 @@ struct Pipeline {
   std::string ckptDir;  // checkpoints (pbEnsemblePipelineSetCheckpoint); empty: none
   bool resume = false;
   bool started = false;
+  // One placement per distinct blob: members whose Particlebot::placementKey() agree -- a sweep of
+  // nDead, light position, ... under one seed -- are placed once; the others take a copy of the placed state and of
+  // the private generator's state after the placement, so every member is bit-identical to its stand-alone run.
+  // keyOf[k] indexes `shared` (-1: this member's key is unique, or sharing is off: PB_SHARE_PLACEMENTS=0).
+  struct SharedPlacement {
+    int state = 0;      // 0 nobody has started it, 1 being placed, 2 ready, -1 failed
+    int usesLeft = 0;   // members that still have to take it (freed at 0)
+    int firstMember = 0;
+    Particlebot::Placement placed;
+  };
+  std::vector<int> keyOf;
+  std::vector<SharedPlacement> shared;
+  std::condition_variable cvPlaced;
+  int placementsRun = 0, placementsShared = 0;
+
+  // (calling thread, before the pool starts) group the members by placement key; a member whose configuration does
+  // not load keeps -1 and fails in its producer as before
+  void groupPlacements() {
+    keyOf.assign(nmembers, -1);
+    const char *env = getenv("PB_SHARE_PLACEMENTS");
+    if ((env && env[0] == '0') || resume) return;
+    std::map<std::string, std::vector<int>> groups;
+    const char *cp = haveCfg ? cfgPath.c_str() : nullptr, *co = common.empty() ? nullptr : common.c_str();
+    for (int k = 0; k < nmembers; k++) {
+      // (the key needs the configuration only, not a Particlebot with its host arrays)
+      PbRunConfig c;
+      c.params.seed = 0;
+      if (cp && !c.loadFile(cp)) continue;
+      applyOverrides(c, co);
+      applyOverrides(c, over[k].c_str());
+      c.derive();
+      groups[Particlebot::placementKeyOf(c.params, c.hex_spacing, c.square_lattice, c.fast_blob)].push_back(k);
+    }
+    for (auto &g : groups) {
+      if (g.second.size() < 2) continue;
+      SharedPlacement sp;
+      sp.usesLeft = (int)g.second.size();
+      sp.firstMember = g.second.front();
+      for (int k : g.second) keyOf[k] = (int)shared.size();
+      shared.push_back(std::move(sp));
+    }
+  }
+
+  // Place shared blob `g` on this thread from member `k`'s configuration (its placement inputs are the group's) and
+  // publish it.  Returns the member built along the way (placed, dead draw not yet done) or nullptr on failure.
+  Member *placeShared(int g, int k) {
+    Member *m = new Member();
+    const char *cp = haveCfg ? cfgPath.c_str() : nullptr, *co = common.empty() ? nullptr : common.c_str();
+    Particlebot::Placement placed;
+    const bool ok = buildMember(*m, cp, co, over[k].c_str(), nullptr, &placed);
+    std::lock_guard<std::mutex> lock(mu);
+    SharedPlacement &sp = shared[g];
+    if (ok) {
+      sp.placed = std::move(placed);
+      sp.state = 2;
+      placementsRun++;
+    } else {
+      sp.state = -1;
+    }
+    cvPlaced.notify_all();
+    if (!ok) {
+      delete m;
+      return nullptr;
+    }
+    return m;
+  }
+
+  // Member k of a shared group: take the group's placement, placing it first if nobody has.  While another thread is
+  // placing it, this thread does not idle: it places the next group ahead that nobody has started (its members will
+  // find it ready), then looks again.
+  Member *buildShared(int k) {
+    const int g = keyOf[k];
+    for (;;) {
+      int other = -1, otherMember = -1;
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        SharedPlacement &sp = shared[g];
+        if (sp.state == 0) {
+          sp.state = 1;
+          lock.unlock();
+          Member *m = placeShared(g, k);   // this member IS the one built along the way
+          if (m) releaseShared(g);
+          return m;
+        }
+        if (sp.state == -1) return nullptr;
+        if (sp.state == 2) break;
+        // being placed elsewhere: look ahead for work
+        for (int j = k + 1; j < nmembers && other < 0; j++)
+          if (keyOf[j] >= 0 && shared[keyOf[j]].state == 0) other = keyOf[j], otherMember = j;
+        if (other >= 0) {
+          shared[other].state = 1;
+        } else {
+          cvPlaced.wait(lock, [&] { return stop || failed || shared[g].state != 1; });
+          if (stop || failed) return nullptr;
+          continue;
+        }
+      }
+      delete placeShared(other, otherMember);   // (only the placement is kept; member `otherMember` is built in its turn)
+    }
+    Member *m = new Member();
+    const char *cp = haveCfg ? cfgPath.c_str() : nullptr, *co = common.empty() ? nullptr : common.c_str();
+    // (state 2 entries are immutable until their last user has released them: read without the lock)
+    if (!buildMember(*m, cp, co, over[k].c_str(), &shared[g].placed)) {
+      delete m;
+      return nullptr;
+    }
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      placementsShared++;
+    }
+    releaseShared(g);
+    return m;
+  }
+  void releaseShared(int g) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (--shared[g].usesLeft == 0) shared[g].placed = Particlebot::Placement();
+  }
 
   void producer(int tid) {
     for (;;) {
@@ -976,8 +1122,17 @@ struct Pipeline {
       }
       if (ok && !restored) {
         delete m;
-        m = new Member();
-        ok = buildMember(*m, cp, co, over[k].c_str());
+        if (keyOf[k] >= 0) {
+          m = buildShared(k);
+          ok = m != nullptr;
+        } else {
+          m = new Member();
+          ok = buildMember(*m, cp, co, over[k].c_str());
+          if (ok) {
+            std::lock_guard<std::mutex> lock(mu);
+            placementsRun++;
+          }
+        }
       }
       cpuSeconds[tid] += threadCpuSeconds() - c0;
       wallSeconds[tid] += nowSeconds() - t0;
@@ -991,6 +1146,7 @@ struct Pipeline {
       }
       cvReady.notify_all();
       cvRoom.notify_all();
+      cvPlaced.notify_all();
     }
   }
   void start() {
@@ -1014,6 +1170,7 @@ struct Pipeline {
     }
     cvRoom.notify_all();
     cvReady.notify_all();
+    cvPlaced.notify_all();
     for (auto &th : pool) th.join();
     pool.clear();
     for (auto *&m : built) {
@@ -1133,6 +1290,16 @@ void *pbEnsemblePipelineCreateCheckpointed(const char *cfg_path, const char *com
     }
   }
   int autoSub = pbEnsemblePipelineAutoSubBatch(botsPerMember, p->threads);
+  // Members that share their placement cost the pool one placement per group, not one per member: when most members
+  // are copies (a parameter sweep under a few seeds), the "whole placement rounds of the pool" bound above says
+  // nothing -- a one-producer rank would step sub-batches of 4 members of 10^5 bots, paying a launch's ramp and drain
+  // on a tenth of the chip -- and the cache target alone sizes the sub-batch.
+  p->resume = resume != 0 && checkpoint_dir && checkpoint_dir[0];
+  p->groupPlacements();
+  int distinct = (int)p->shared.size();
+  for (int k : p->keyOf) distinct += k < 0 ? 1 : 0;
+  if (distinct * 4 <= nmembers)
+    autoSub = std::max(autoSub, pbEnsemblePipelineAutoSubBatch(botsPerMember, 1 << 20));
   // The automatic decomposition steps TWO sub-batches of half that size at the same time (a launch's ramp and drain
   // overlap the other sub-batch's steady state, and together they still fit the Infinity Cache: configs[4] slice of
   // 240 members, one pipeline of 30-member sub-batches 22.0 s, two lanes of 15 21.2 s, three of 10 21.1 s;
@@ -1256,6 +1423,15 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
         return true;
       });
       if (p->failed) return -1;
+      // refuse a run whose rows cannot fit BEFORE its first step, not hours into it
+      const PbRunConfig &c0 = *p->built[first]->cfg;
+      const long need = out ? rowsNeeded(c0.timestep, c0.dump_interval, c0.params.max_time, max_steps, max_rows) : 0;
+      if (need > max_rows) {
+        fprintf(stderr, "pbEnsemblePipelineRun: the run writes more than %d summary rows per member (dump_interval %g, "
+                "max_time %g) and the row buffer holds %d: raise max_rows (particlebot_ensemble --max-rows) or the dump "
+                "interval; nothing was stepped\n", max_rows, (double)c0.dump_interval, (double)c0.params.max_time, max_rows);
+        return -1;
+      }
       for (int k = first; k < first + count; k++) {
         e.members.push_back(p->built[k]);
         p->built[k] = nullptr;
@@ -1376,6 +1552,10 @@ long pbEnsemblePipelineRun(void *pv, long max_steps, float *out, int max_rows, i
   p->tm.placement_cpu_s = p->tm.placement_thread_wall_s = 0.0;
   for (double c : p->cpuSeconds) p->tm.placement_cpu_s += c;
   for (double c : p->wallSeconds) p->tm.placement_thread_wall_s += c;
+  {
+    std::lock_guard<std::mutex> lock(p->mu);
+    p->tm.placements_run = p->placementsRun, p->tm.placements_shared = p->placementsShared;
+  }
   if (rows) *rows = nrowsAll;
   if (timings) *timings = p->tm;
   return steps;
@@ -1435,6 +1615,14 @@ int pbEnsemblePipelineDryRun(void *pv, int dwell_ms, unsigned long long *checksu
 }
 
 unsigned pbEnsemblePipelineNumBots(void *pv) { return ((Pipeline *)pv)->nbots; }
+
+void pbEnsemblePipelinePlacementCounts(void *pv, int *run, int *shared) {
+  Pipeline *p = (Pipeline *)pv;
+  if (!p) return;
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (run) *run = p->placementsRun;
+  if (shared) *shared = p->placementsShared;
+}
 
 int pbEnsemblePipelineGetState(void *pv, int member, float *pos, float *vel, float *rad) {
   Pipeline *p = (Pipeline *)pv;

@@ -35,6 +35,8 @@
 // This translation unit holds the object, the schedule and the re-sort / phase-update / I/O kernels; the
 // force kernels live in pb_force.hip (exact, all forms), pb_stream.hip (streamlined) and pb_resident.hip.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -440,6 +442,56 @@ inline bool gate(float t, float interval, float dt) {
   return t - interval * floorf(t / interval) < dt;
 }
 
+// Trips per wave of the streamlined kernel's neighbour loop under its two walks (pb_stream.hip, WALK), summed over all
+// waves: out[0] row by row (per stencil row the longest range of the wave's 64 lanes), out[1] flattened (the longest
+// LIST of the wave's lanes).  Run at a re-sort; the host keeps the flattened walk when it saves enough trips.
+__global__ __launch_bounds__(TILE) void k_walk_trips(const PbDevParams *__restrict__ params, const float4 *__restrict__ pr,
+                                                     const uint32_t *__restrict__ cellSAll, uint32_t n,
+                                                     unsigned long long *__restrict__ out) {
+  const PbDevParams &P = params[blockIdx.y];
+  uint32_t l = blockIdx.x * TILE + threadIdx.x;
+  const bool alive = l < n;
+  if (!alive) l = n - 1u;
+  const uint32_t *__restrict__ cellS = cellSAll + (size_t)blockIdx.y * (P.numCells + 1u);
+  const float4 me = pr[blockIdx.y * n + l];
+  const int gx = pbCellX(P, me.x), gy = pbCellY(P, me.y);
+  const uint32_t GX = P.gridX;
+  const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
+  const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;
+  uint32_t rows = 0, list = 0;
+  for (int r = 0; r < 5; r++) {
+    const uint32_t row = ((uint32_t)(gy + r - 2) & (P.gridY - 1u)) << P.gridXLog2;
+    uint32_t len = cellS[row + mx0 + first] - cellS[row + mx0];
+    if (first < 5u) len += cellS[row + 5u - first] - cellS[row];  // the part of the row behind the x-wrap
+    if (!alive) len = 0u;
+    list += len;
+    for (int d = 1; d < 64; d <<= 1) len = max(len, (uint32_t)__shfl_xor((int)len, d));
+    rows += len;
+  }
+  for (int d = 1; d < 64; d <<= 1) list = max(list, (uint32_t)__shfl_xor((int)list, d));
+  if ((threadIdx.x & 63u) == 0u) {
+    atomicAdd(&out[0], (unsigned long long)rows);
+    atomicAdd(&out[1], (unsigned long long)list);
+  }
+}
+
+// The automatic choice of k_force_stream's walk for this batch, from its current cell lists: flattened when that
+// saves at least 7 % of the trips (blobs: -13 ... -20 %; the bench lattice: ~0, where the row-by-row walk's better
+// cache-line sharing wins).  Either walk gives the same bits.
+int chooseStreamWalk(pbSim *S) {
+  if (!S->haveCells) return PB_OK;
+  if (!S->walkTrips) PB_TRY(hipMalloc((void **)&S->walkTrips, 2 * sizeof(unsigned long long)));
+  PB_TRY(hipMemsetAsync(S->walkTrips, 0, 2 * sizeof(unsigned long long), S->stream));
+  hipLaunchKernelGGL(k_walk_trips, gridOf(S), dim3(TILE), 0, S->stream, S->dP, S->pr[S->cur], S->cellS, S->n, S->walkTrips);
+  PB_TRY(hipGetLastError());
+  unsigned long long t[2] = {0, 0};
+  PB_TRY(hipMemcpyAsync(t, S->walkTrips, sizeof t, hipMemcpyDeviceToHost, S->stream));
+  PB_TRY(hipStreamSynchronize(S->stream));
+  S->walkTripsHost[0] = t[0], S->walkTripsHost[1] = t[1];
+  S->streamWalkAuto = t[1] * 100ull < t[0] * 93ull;
+  return PB_OK;
+}
+
 int resort(pbSim *S) {
   const uint32_t n = S->n;
   const int c = S->cur, o = c ^ 1;
@@ -460,6 +512,7 @@ int resort(pbSim *S) {
   S->haveCells = true;
   S->sortedKeys = S->keys[where];
   S->stats.resorts++;
+  if (S->variant == 3 && S->streamWalk < 0) return chooseStreamWalk(S);
   return PB_OK;
 }
 
@@ -467,15 +520,18 @@ int resort(pbSim *S) {
 // decided yet -- the first use seeds it from PB_MIN_DISTANCE_MODE (0 or 1; anything else: 0), a default that CHILD
 // processes inherit (tests/conftest.py exports it when this host's libm fails the check, so that the binaries the
 // tests spawn take the reference's host loop too).  An explicit pbSetMinDistanceMode always wins over the environment.
-int g_minDistanceMode = -1;
+// (atomic: the two lanes of an ensemble pipeline create their batches on two threads at once, and an explicit
+//  pbSetMinDistanceMode may arrive from a third; the compare-exchange lets a concurrent explicit setting win)
+std::atomic<int> g_minDistanceMode{-1};
 static int minDistanceDefault() {
-  if (g_minDistanceMode < 0) {
+  int cur = g_minDistanceMode.load(std::memory_order_acquire);
+  if (cur < 0) {
     int m = 0;
     if (const char *v = getenv("PB_MIN_DISTANCE_MODE"))
       if ((v[0] == '0' || v[0] == '1') && v[1] == 0) m = v[0] - '0';
-    g_minDistanceMode = m;
+    if (g_minDistanceMode.compare_exchange_strong(cur, m, std::memory_order_acq_rel)) cur = m;
   }
-  return g_minDistanceMode;
+  return cur;
 }
 
 int phaseUpdate(pbSim *S) {
@@ -655,6 +711,7 @@ void pbSimDestroy(pbSim *S) {
   (void)hipFree(S->comPos);
   (void)hipFree(S->comPartial);
   (void)hipFree(S->comOut);
+  (void)hipFree(S->walkTrips);
   if (S->hMin) (void)hipHostFree(S->hMin);
   if (S->hMinD) (void)hipHostFree(S->hMinD);
   if (S->hCom) (void)hipHostFree(S->hCom);
@@ -737,6 +794,7 @@ int pbSimCreateBatch(pbSim **out, const SimParams *params, int nsims, float wall
     if (const char *v = getenv("PB_DEBUG_FORCE_BIG")) S->wideOffsets = atoi(v) != 0;
     if (const char *v = getenv("PB_XCD_MEMBERS")) S->xcdMembers = atoi(v) != 0;
     if (const char *v = getenv("PB_XCD_TILES_ALL")) S->xcdTilesAll = atoi(v) != 0;
+    if (const char *v = getenv("PB_STREAM_WALK")) rc |= pbSimSetStreamWalk(S, atoi(v));
     if (rc != PB_OK) {
       pbLastError() = "pbSimCreateBatch: PB_FORCE_VARIANT / PB_LANES_PER_BOT / PB_RESIDENT out of range";
       delete S;
@@ -1021,16 +1079,37 @@ int pbSimStep(pbSim *S, float deltaTime, float sort_interval, int nsteps, int *s
 int pbSimStepTimed(pbSim *S, float deltaTime, float sort_interval, int nsteps, int *steps_done,
                    float *elapsed_ms) {
   if (!S || nsteps < 0) return PB_ERR_ARG;
+  // PB_TIMED_TRACE=1 (diagnostic): where the host's time around a timed region goes, in microseconds from entry
+  static const bool trace = [] { const char *v = getenv("PB_TIMED_TRACE"); return v && v[0] == '1'; }();
+  const auto h0 = std::chrono::steady_clock::now();
+  auto us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count(); };
   useDevice(S);
   if (steps_done) *steps_done = 0;
   PB_TRY(hipEventRecord(S->ev0, S->stream));
+  const double tRec0 = us();
   const int rc = stepMany(S, deltaTime, sort_interval, nsteps, steps_done);
   if (rc) return rc;
+  const double tLaunched = us();
   PB_TRY(hipEventRecord(S->ev1, S->stream));
+  const double tRec1 = us();
+  // A measurement API: the caller's wall clock around this call should see the device time, not the wake-up latency of
+  // an interrupt-driven wait.  So the host polls the event (about a microsecond per query) for as long as a short
+  // region lasts, and only then falls back to the blocking wait.
+  {
+    const auto spin0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    while ((q = hipEventQuery(S->ev1)) == hipErrorNotReady)
+      if (std::chrono::steady_clock::now() - spin0 > std::chrono::milliseconds(250)) break;
+    if (q != hipSuccess && q != hipErrorNotReady) PB_TRY(q);
+  }
+  const double tDone = us();
   PB_TRY(hipEventSynchronize(S->ev1));
   float ms = 0.0f;
   PB_TRY(hipEventElapsedTime(&ms, S->ev0, S->ev1));
   if (elapsed_ms) *elapsed_ms = ms;
+  if (trace)
+    fprintf(stderr, "pbSimStepTimed: %d steps: ev0 recorded %.1f us, launches issued %.1f, ev1 recorded %.1f, event complete "
+            "%.1f, return %.1f; device %.1f us\n", nsteps, tRec0, tLaunched, tRec1, tDone, us(), ms * 1e3);
   return PB_OK;
 }
 
@@ -1091,7 +1170,30 @@ int pbSimGetStats(pbSim *S, pbSimStats *stats) {
 
 int pbSimSetForceVariant(pbSim *S, int variant) {
   if (!S || variant < 0 || variant > 3) return PB_ERR_ARG;
+  const bool becomes3 = variant == 3 && S->variant != 3;
   S->variant = variant;
+  // (a batch that already has its cell lists: the walk of the streamlined kernel is chosen now, not at the next re-sort)
+  if (becomes3 && S->streamWalk < 0 && S->haveCells) {
+    useDevice(S);
+    return chooseStreamWalk(S);
+  }
+  return PB_OK;
+}
+
+int pbSimSetStreamWalk(pbSim *S, int mode) {
+  if (!S || mode < -1 || mode > 1) return PB_ERR_ARG;
+  S->streamWalk = mode;
+  if (mode < 0 && S->variant == 3 && S->haveCells) {
+    useDevice(S);
+    return chooseStreamWalk(S);
+  }
+  return PB_OK;
+}
+
+int pbSimGetStreamWalkTrips(pbSim *S, unsigned long long *rowByRow, unsigned long long *flattened) {
+  if (!S) return PB_ERR_ARG;
+  if (rowByRow) *rowByRow = S->walkTripsHost[0];
+  if (flattened) *flattened = S->walkTripsHost[1];
   return PB_OK;
 }
 
@@ -1131,6 +1233,7 @@ int pbSimGetConfig(pbSim *S, pbSimConfig *cfg) {
   cfg->offsets64 = (!p.stream && p.big) ? 1 : 0;
   cfg->attraction_sums = attractionSumsKept(S) ? 1 : 0;
   cfg->dead_sum_form = ((cfg->resident || p.stream) ? !attractionSumsKept(S) : !p.asum) ? 1 : 0;
+  cfg->stream_walk = (p.stream && pbStreamWalk(S)) ? 1 : 0;
   return PB_OK;
 }
 
@@ -1159,7 +1262,7 @@ int pbSimSetMinDistanceMode(pbSim *S, int mode) {
 
 int pbSetMinDistanceMode(int mode) {
   if (mode < 0 || mode > 1) return PB_ERR_ARG;
-  g_minDistanceMode = mode;
+  g_minDistanceMode.store(mode, std::memory_order_release);
   return PB_OK;
 }
 

@@ -80,6 +80,11 @@ struct pbSim {
   int variant = 2;  // force kernel: 0 reference-shaped branches, 1 branch-free, 2 (default) + fast exact math
   int resident = 0;     // 0 automatic, 1 never, 2 whenever the simulation fits one workgroup (n <= 1024)
   int lanesPerBot = 0;  // lanes per bot of the per-step force kernel: 0 automatic; 1 (throughput form), 2, 4, 8, 16
+  // k_force_stream's neighbour walk (pb_stream.hip, WALK): -1 chosen at every re-sort from the batch's cell lists
+  // (chooseStreamWalk), 0 row by row, 1 flattened (pbSimSetStreamWalk).  Bit-identical either way.
+  int streamWalk = -1;
+  bool streamWalkAuto = false;
+  unsigned long long *walkTrips = nullptr, walkTripsHost[2] = {0, 0};
   bool wideOffsets = false;  // run the 64-bit-offset throughput sweep on a batch below 2^28 bots (pbSimSelectForceForm, tests)
   unsigned debugLdsBytes = 0;  // PB_DEBUG_LDS_BYTES under PB_ALLOW_ENV_OVERRIDES=1 (tools/occupancy_sweep.py --lds)
   int rng = 0;          // phase noise: 0 PB-RNG v1 (counter based), 1 cuRAND-compatible XORWOW (pb_xorwow.hpp)
@@ -97,6 +102,7 @@ static inline dim3 gridOf(const pbSim *S) { return dim3(cdiv(S->n, TILE), S->nsi
 static inline void useDevice(const pbSim *S) { (void)hipSetDevice(S->device); }
 
 // absForce_a has a reader (impl.cuh:167-169) or the caller asked for it (pbSimSetForceSums)
+static inline bool pbStreamWalk(const pbSim *S) { return S->streamWalk >= 0 ? S->streamWalk == 1 : S->streamWalkAuto; }
 static inline bool attractionSumsKept(const pbSim *S) { return S->forceSums != 0 || S->anyConstrained; }
 
 // What a per-step force launch of this batch will be: the streamlined kernel or an exact one
@@ -115,6 +121,9 @@ PbForcePlan pbForcePlan(const pbSim *S);
 // step n's forces + kick into the other copy of posrad/vel; fuse: also step n+1's radius + integration
 void pbLaunchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext);          // pb_force.hip
 void pbLaunchForceStream(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext);    // pb_stream.hip
+// profiler-style names of the kernels above ("k_force<...>(argument types)"): pbSimForceKernelName
+std::string pbKernelArgs(const char *mangledPointerType);                                                // pb_force.hip
+std::string pbForceStreamName(const pbSim *S);                                                           // pb_stream.hip
 // m whole timesteps from time t0 in one launch (simulations of <= 1024 bots)
 bool pbResidentWanted(const pbSim *S);                                                                    // pb_resident.hip
 void pbLaunchResident(pbSim *S, float dt, float t0, int m, int lightWave);

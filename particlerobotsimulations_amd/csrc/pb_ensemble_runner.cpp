@@ -239,8 +239,8 @@ int main(int argc, char **argv) {
   std::string cfgPath, outPath, rendezvous, ckptDir, csvDir;
   std::vector<std::pair<std::string, std::string>> sets;
   std::vector<std::pair<std::string, std::vector<std::string>>> sweeps;  // --sweep may be given several times
-  int members = 32, subBatch = 0, hostThreads = 0;
-  bool resume = false, rendezvousTest = false;
+  int members = 32, subBatch = 0, hostThreads = 0, maxRows = 4096;
+  bool resume = false, rendezvousTest = false, cartesian = false;
   long seed0 = 1000;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--members") && i + 1 < argc) members = atoi(argv[++i]);
@@ -251,6 +251,8 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--rendezvous-test")) rendezvousTest = true;
     else if (!strcmp(argv[i], "--sub-batch") && i + 1 < argc) subBatch = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) hostThreads = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--max-rows") && i + 1 < argc) maxRows = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--cartesian")) cartesian = true;
     else if (!strcmp(argv[i], "--checkpoint") && i + 1 < argc) ckptDir = argv[++i];
     else if (!strcmp(argv[i], "--resume") && i + 1 < argc) {
       ckptDir = argv[++i];
@@ -264,7 +266,8 @@ int main(int argc, char **argv) {
     } else if (argv[i][0] != '-' && cfgPath.empty()) cfgPath = argv[i];
     else {
       fprintf(stderr, "usage: %s <config.cfg> --members M [--seed0 S] [--set NAME VALUE]... [--sweep KEY V1 V2 ...]... "
-                      "[--out FILE] [--csv-dir DIR] [--sub-batch B] [--host-threads T] [--checkpoint DIR | --resume DIR] "
+                      "[--cartesian] [--max-rows R] [--out FILE] [--csv-dir DIR] [--sub-batch B] [--host-threads T] "
+                      "[--checkpoint DIR | --resume DIR] "
                       "[--rendezvous FILE (single host)]\n", argv[0]);
       return 2;
     }
@@ -273,8 +276,8 @@ int main(int argc, char **argv) {
     fprintf(stderr, "particlebot_ensemble: --csv-dir cannot be combined with --checkpoint / --resume\n");
     return 2;
   }
-  if (!rendezvousTest && (cfgPath.empty() || members < 1)) {
-    fprintf(stderr, "particlebot_ensemble: a configuration file and --members >= 1 are required\n");
+  if (!rendezvousTest && (cfgPath.empty() || members < 1 || maxRows < 1)) {
+    fprintf(stderr, "particlebot_ensemble: a configuration file, --members >= 1 and --max-rows >= 1 are required\n");
     return 2;
   }
   const char *rankNames[] = {"RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID", nullptr};
@@ -357,17 +360,28 @@ int main(int argc, char **argv) {
   std::string common;
   for (auto &kv : sets) common += kv.first + "\n" + kv.second + "\n";
   std::vector<std::string> over;
+  // --cartesian: the swept keys form a grid (first --sweep fastest) and every grid point runs under each seed --
+  // member k is grid point k mod G under seed seed0 + k / G, G = the product of the sweeps' lengths -- so that
+  // `--members 1024 --sweep nDead <64 values> --cartesian` is BASELINE configs[4]'s "64 points x 16 seeds".  Members of
+  // one seed then share their placement (the pipeline places each distinct blob once).
+  long grid = 1;
+  for (auto &sw : sweeps)
+    if (cartesian && !sw.second.empty()) grid *= (long)sw.second.size();
   for (int k = rank; k < members; k += world) {
-    std::string o = "seed\n" + std::to_string(seed0 + k);
+    std::string o = "seed\n" + std::to_string(seed0 + (cartesian ? k / grid : k));
     // (in the order given; a later key wins, so `--sweep seed ...` replaces seed0 + k)
-    for (auto &sw : sweeps)
-      if (!sw.first.empty() && !sw.second.empty()) o += "\n" + sw.first + "\n" + sw.second[(size_t)k % sw.second.size()];
+    long stride = 1;
+    for (auto &sw : sweeps) {
+      if (sw.first.empty() || sw.second.empty()) continue;
+      const size_t len = sw.second.size();
+      o += "\n" + sw.first + "\n" + sw.second[cartesian ? (size_t)((k % grid) / stride) % len : (size_t)k % len];
+      stride *= (long)len;
+    }
     over.push_back(o);
   }
   std::vector<const char *> overPtr;
   for (auto &o : over) overPtr.push_back(o.c_str());
   const int mine = (int)over.size(), per = pbEnsembleShard(members, 0, world);
-  const int maxRows = 4096;
   std::vector<float> rows((size_t)(mine ? mine : 1) * maxRows * 4, 0.0f);
   int nrows = 0, failed = 0;
   long steps = 0;

@@ -3,8 +3,12 @@
 //
 // Reference: collideD + collideCell + collideSpheres (particlebot_kernel_impl.cuh:541-831) and, fused,
 // the next step's updateRad_light_wave (:124-181) and integrate_functor (:53-103).
+#include <cxxabi.h>
+
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <typeinfo>
 
 #include "pb_engine.hpp"
 
@@ -146,18 +150,34 @@ void launchForceT(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int 
                      S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->orig[c], tNext, doRadiusNext, (int)fuse);
 }
 
+// The kernel's name as a profiler prints it -- "k_force<false, true, 1, 1, false, true>(PbDevParams const*, ...)" --
+// built from the instantiation's own type, so that a committed rocprofv3 summary can be matched against the
+// LOADED library (bench.py drops a profile's counters when the signatures differ: an argument reorder or a new
+// template parameter makes the counters another kernel's).
+template <bool PAYLOAD, bool FLAT, int L, bool BIG, bool ASUM>
+std::string forceNameT() {
+  constexpr int NB = (FLAT && L == 1 && !BIG && ASUM) ? PB_THROUGHPUT_NB : 1;
+  auto b = [](bool v) { return std::string(v ? "true" : "false"); };
+  return "k_force<" + b(PAYLOAD) + ", " + b(FLAT) + ", " + std::to_string(L) + ", " + std::to_string(NB) + ", " + b(BIG) +
+         ", " + b(ASUM) + ">" + pbKernelArgs(typeid(&k_force<PAYLOAD, FLAT, L, NB, BIG, ASUM>).name());
+}
+
 // ---- the forms table ---------------------------------------------------------------------------
 // Every shape of the exact kernel that can run, once.  The dispatch below looks a launch up here, the
 // C-ABI hands the rows to the parity tests (pbForceFormCount / pbForceFormGet / pbSimSelectForceForm),
 // so a form cannot exist without being enumerable.  Each row is instantiated for both payload modes.
 using LaunchFn = void (*)(pbSim *, bool, int, int, float, float, int);
+using NameFn = std::string (*)();
 struct FormRow {
   pbForceForm form;
   LaunchFn launch[2];  // [payload]
+  NameFn name[2];
 };
 #define PB_FORM(FL, LL, AS, BG)                                                        \
   {{FL, LL, AS, BG}, {launchForceT<false, (FL) != 0, LL, (BG) != 0, (AS) != 0>,        \
-                      launchForceT<true, (FL) != 0, LL, (BG) != 0, (AS) != 0>}}
+                      launchForceT<true, (FL) != 0, LL, (BG) != 0, (AS) != 0>},        \
+                     {forceNameT<false, (FL) != 0, LL, (BG) != 0, (AS) != 0>,          \
+                      forceNameT<true, (FL) != 0, LL, (BG) != 0, (AS) != 0>}}
 const FormRow kForms[] = {
     PB_FORM(0, 1, 1, 0),  // reference-shaped branches (force variant 0)
     PB_FORM(1, 1, 1, 0),  PB_FORM(1, 1, 0, 0),   // throughput form: one bot per lane
@@ -211,6 +231,16 @@ PbForcePlan pbForcePlan(const pbSim *S) {
   return p;
 }
 
+std::string pbKernelArgs(const char *mangledPointerType) {
+  // "void (*)(PbDevParams const*, ...)" -> "(PbDevParams const*, ...)"
+  int status = 0;
+  char *d = abi::__cxa_demangle(mangledPointerType, nullptr, nullptr, &status);
+  std::string t = (status == 0 && d) ? d : mangledPointerType;
+  free(d);
+  const size_t at = t.find("(*)");
+  return at == std::string::npos ? t : t.substr(at + 3);
+}
+
 void pbLaunchForce(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext) {
   const PbForcePlan plan = pbForcePlan(S);
   if (plan.stream) return pbLaunchForceStream(S, fuse, c, o, dt, tNext, doRadiusNext);
@@ -229,6 +259,28 @@ int pbForceFormCount(void) { return kNumForms; }
 int pbForceFormGet(int index, pbForceForm *form) {
   if (index < 0 || index >= kNumForms || !form) return PB_ERR_ARG;
   *form = kForms[index].form;
+  return PB_OK;
+}
+
+int pbForceFormKernelName(int index, int payload, char *buf, size_t cap) {
+  if (index < 0 || index >= kNumForms || !buf) return PB_ERR_ARG;
+  const std::string name = kForms[index].name[payload ? 1 : 0]();
+  if (name.size() + 1 > cap) return PB_ERR_ARG;
+  memcpy(buf, name.c_str(), name.size() + 1);
+  return PB_OK;
+}
+
+int pbSimForceKernelName(pbSim *S, char *buf, size_t cap) {
+  if (!S || !buf || cap == 0) return PB_ERR_ARG;
+  const PbForcePlan plan = pbForcePlan(S);
+  std::string name;
+  if (plan.stream) name = pbForceStreamName(S);
+  for (const FormRow &r : kForms)
+    if (!plan.stream && r.form.flat == (plan.kind != 0) && r.form.lanes_per_bot == plan.form &&
+        (r.form.attraction_sums != 0) == plan.asum && (r.form.offsets64 != 0) == plan.big)
+      name = r.name[S->payload ? 1 : 0]();
+  if (name.empty() || name.size() + 1 > cap) return PB_ERR_ARG;
+  memcpy(buf, name.c_str(), name.size() + 1);
   return PB_OK;
 }
 

@@ -26,6 +26,10 @@ __global__ __launch_bounds__(1024) void k_resident(const PbDevParams *__restrict
   __shared__ float2 sVel[2][CAP + 1];
   constexpr bool REPLIST = L == 1 && (!ASUM || PB_ASUM_XY);  // (as k_force: the one-lane-per-bot sweep parks contact magnitudes)
   __shared__ float repLds[REPLIST ? (PB_REP_CAP + 1) * 1024 : 1];
+  // L == 1 (members of 513 ... 1024 bots): 32.8 + 16.4 + 36.9 = 86 KB of the CU's 160 KB, i.e. ONE workgroup per CU.
+  // Registers allow a second one only below 768 bots (>= 71 VGPRs: 6 waves per SIMD) and only a batch of more than
+  // 256 such members would use it; tests/test_code_objects.py pins the figure.
+  static_assert(sizeof(sPr) + sizeof(sVel) + sizeof(repLds) <= 160 * 1024, "k_resident: LDS beyond one CU");
   float *const repCol = &repLds[REPLIST ? threadIdx.x : 0];
   const PbDevParams &P = params[blockIdx.x];
   const uint32_t l = threadIdx.x / L, sub = threadIdx.x % L;
@@ -150,8 +154,10 @@ void launchResidentT(pbSim *S, float dt, float t0, int m, int lightWave) {
 
 void pbLaunchResident(pbSim *S, float dt, float t0, int m, int lightWave) {
   const bool asum = attractionSumsKept(S);
-  // (with both sums kept the one-lane-per-bot sweep roots its attraction magnitudes without a domain check)
-  const bool fast = S->variant >= 2 && S->fastOk && (!asum || S->magOk);
+  // (with both sums kept the ONE-lane-per-bot sweep roots its attraction magnitudes without a domain check,
+  //  pbAttractionMagnitudeSafe; the multi-lane forms do not and keep the fast path whatever magOk says -- as k_force)
+  const bool magNeeded = asum && residentLanes(S->n) == 1 && PB_ASUM_XY;
+  const bool fast = S->variant >= 2 && S->fastOk && (!magNeeded || S->magOk);
 #define PB_RESL(PL, FA)                                                   \
   do {                                                                    \
     if (asum) launchResidentT<PL, FA, true>(S, dt, t0, m, lightWave);     \

@@ -2,6 +2,8 @@
 // of the engine that is not bit-identical to the reference restatement (DESIGN.md section 5
 // "Streamlined arithmetic"; SURVEY.md 8(d) caveat 1).  Reference: collideD / collideSpheres
 // (particlebot_kernel_impl.cuh:541-831), arithmetic algebraically streamlined.
+#include <typeinfo>
+
 #include "pb_engine.hpp"
 
 namespace {
@@ -26,6 +28,10 @@ namespace {
 #ifndef PB_STREAM_CAP
 #define PB_STREAM_CAP 12  // contacts per lane listed in LDS (further ones are evaluated in place)
 #endif
+#ifndef PB_STREAM_CAP_WALK
+#define PB_STREAM_CAP_WALK 10  // the same in the flattened-walk form: 10 KB + the 10 KB range queue = 8 workgroups per CU
+#endif
+#define PB_WALK_QUEUE 5  // queue entries per lane: ranges 1..4 of the compacted list + the sentinel
 
 // static/kinetic friction and the velocity update (impl.cuh:801-825), streamlined: squared comparisons instead
 // of two square roots, the kinetic-friction unit vector from one v_rsq_f32
@@ -101,7 +107,19 @@ PB_DEV float pbActuateS(const PbDevParams &P, float rad, float phase, int dead, 
 // co-limits this kernel), but the staging prologue, the 40 KB of LDS per workgroup and the waves that need more than
 // one tile (grid-row ends, the bench lattice's alternating row densities) gave it all back: 49.3 us in the best
 // case, 60-78 us as a complete kernel.  Not shipped.
-template <bool PAYLOAD, bool ASUM>
+// WALK (round 5 experiment, shipped for this kernel in round 6; profiles/r5_blob_walk.txt, profiles/r6_blob_v3.*): how a
+// lane visits its 25-cell stencil.
+//   false  row by row: the wave advances stencil row by stencil row and runs the LONGEST row of its 64 lanes each time
+//          (trips per wave = sum over the five rows of the longest range): lane utilisation 0.95 on the bench lattice,
+//          0.73 on BASELINE configs[4]'s blobs, whose cell occupancies vary
+//   true   flattened: every lane walks its own five ranges back to back (trips per wave = the longest LIST of its 64
+//          lanes).  The non-empty ranges wait in a per-lane queue in LDS; one address iterator runs two elements ahead
+//          of the evaluation and pops the queue when it leaves a range; a lane past the end of its list is masked.
+//          Same candidates in the same order for every bot: BIT-IDENTICAL to WALK false.  -10 % on a 10^6-bot blob,
+//          -7...-9 % on configs[4], 0 % on the lattice (the lanes' lists then no longer line up: 22 instead of 18
+//          distinct cache lines per wave-load).  The host picks it per batch at every re-sort from the trip counts of
+//          both walks (k_walk_trips, pb_engine.hip; pbSimSetStreamWalk pins it).
+template <bool PAYLOAD, bool ASUM, bool WALK>
 __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__restrict__ params,
                                                        const float4 *__restrict__ prIn,
                                                        const float2 *__restrict__ velIn, float4 *__restrict__ prOut,
@@ -110,11 +128,20 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
                                                        float *__restrict__ absR, const uint32_t *__restrict__ orig,
                                                        const uint32_t *__restrict__ cellSAll, uint32_t n, float dt,
                                                        float timeNext, int doRadiusNext, uint32_t perXcd, int fuse) {
-  __shared__ uint32_t contacts[PB_STREAM_CAP][TILE];  // column = lane: conflict-free
+  constexpr int CAP = WALK ? PB_STREAM_CAP_WALK : PB_STREAM_CAP;
+  // one block: the range queue of the flattened walk (uint2 columns) in front of the contact lists (column = lane:
+  // conflict-free)
+  constexpr int QW = WALK ? 2 * PB_WALK_QUEUE : 0;
+  __shared__ __attribute__((aligned(8))) uint32_t ldsBlock[(QW + CAP) * TILE];
+  uint2(*const rangeQ)[TILE] = reinterpret_cast<uint2(*)[TILE]>(ldsBlock);
+  uint32_t(*const contacts)[TILE] = reinterpret_cast<uint32_t(*)[TILE]>(ldsBlock + QW * TILE);
   const PbDevParams &P = params[blockIdx.y];
   const uint32_t tile = perXcd ? (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3) : blockIdx.x;
-  const uint32_t l = tile * TILE + threadIdx.x;
-  if (l >= n) return;
+  uint32_t l = tile * TILE + threadIdx.x;
+  if (!WALK && l >= n) return;
+  // (WALK has wave-wide reductions: a lane beyond the last bot stays, shadows the last bot and stores nothing)
+  const bool alive = l < n;
+  if (WALK && !alive) l = n - 1u;
   const uint32_t s = blockIdx.y * n + l;
   const uint32_t *__restrict__ cellS = cellSAll + (size_t)blockIdx.y * (P.numCells + 1u);
 
@@ -200,7 +227,7 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
       if (contact) {
         const uint32_t j = slotOf();
         if (j != s) {  // (the bot's own slot: a zero force, not worth a trip of the second pass)
-          if (cnt < (uint32_t)PB_STREAM_CAP) contacts[cnt][threadIdx.x] = j;
+          if (cnt < (uint32_t)CAP) contacts[cnt][threadIdx.x] = j;
           else contactOf(j, q);  // list full (pathological compression): evaluate in place
           cnt++;
         }
@@ -217,7 +244,74 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
   const uint32_t mx0 = (uint32_t)(gx - 2) & (GX - 1u);
   const uint32_t first = (GX - mx0) < 5u ? (GX - mx0) : 5u;
   const int nseg = first < 5u ? 2 : 1;
-  {
+  // (wave-uniform) the flattened walk is written for stencil rows that do not wrap in x: one range per row
+  if (WALK && __all(nseg == 1)) {
+    const char *const prBytes = (const char *)prIn;
+    auto at = [&](uint32_t off) __attribute__((always_inline)) { return *(const float4 *)(prBytes + off); };
+    // the five ranges: ten independent cell-table reads, one round trip
+    uint32_t lo[5], hi[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      const uint32_t row = ((uint32_t)(gy + r - 2) & (P.gridY - 1u)) << P.gridXLog2;
+      lo[r] = cellS[row + mx0] * 16u;
+      hi[r] = cellS[row + mx0 + 5u] * 16u;
+    }
+    // compacted list of the non-empty ones, E_0 in registers, E_1 .. E_5 in the lane's LDS column; behind the last
+    // real range the sentinel (0, ~0): the iterator then walks up from the array's first slot and never leaves it
+    // (a list is shorter than the array, so those reads stay inside it; they are never evaluated)
+    uint32_t aEnd = 0xFFFFFFF0u, a0 = 0u, m = 0u, k = 0u;
+    uint2 *const qCol = &rangeQ[0][threadIdx.x];
+#pragma unroll
+    for (int e = 0; e < PB_WALK_QUEUE; e++) qCol[e * TILE] = make_uint2(0u, 0xFFFFFFF0u);
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      if (hi[r] > lo[r]) {
+        m += (hi[r] - lo[r]) >> 4;
+        if (k == 0u) a0 = lo[r], aEnd = hi[r];
+        else qCol[(k - 1u) * TILE] = make_uint2(lo[r], hi[r]);
+        k++;
+      }
+    }
+    if (!alive) m = 0u;
+    // trips of the wave = its longest list
+    uint32_t T = m;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) T = max(T, (uint32_t)__shfl_xor((int)T, d));
+    T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
+    const uint2 *qNext = qCol;
+    // the address iterator: a_k = offset of list element k.  next(a): the element after a -- a + 16, or the first of
+    // the next queued range when that leaves the current one
+    auto next = [&](uint32_t a) __attribute__((always_inline)) {
+      a += 16u;
+      if (a >= aEnd) {
+        const uint2 e = *qNext;
+        qNext += TILE;
+        a = e.x;
+        aEnd = e.y;
+      }
+      return a;
+    };
+    if (T != 0u) {
+      uint32_t a1 = next(a0);
+      float4 q0 = at(a0), q1 = at(a1);
+      uint32_t a2;
+      float4 q2;
+      for (uint32_t t = 0;;) {
+        a2 = next(a1);
+        q2 = at(a2);
+        if (t < m) one(q0, [&]() { return a0 >> 4; });
+        if (++t >= T) break;
+        a0 = next(a2);
+        q0 = at(a0);
+        if (t < m) one(q1, [&]() { return a1 >> 4; });
+        if (++t >= T) break;
+        a1 = next(a0);
+        q1 = at(a1);
+        if (t < m) one(q2, [&]() { return a2 >> 4; });
+        if (++t >= T) break;
+      }
+    }
+  } else {
     // Segment loop rolled and software-pipelined two deep, as in pbSweep: while segment si runs,
     // the cell-table bounds of segment si + 2 and the first two posrad of segment si + 1 are in flight.  Inside a
     // segment posrad loads run two neighbours ahead, three registers rotating roles; the loop runs on 32-bit byte
@@ -263,7 +357,7 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
       }
     }
   }
-  const uint32_t listed = cnt < (uint32_t)PB_STREAM_CAP ? cnt : (uint32_t)PB_STREAM_CAP;
+  const uint32_t listed = cnt < (uint32_t)CAP ? cnt : (uint32_t)CAP;
   for (uint32_t k = 0; k < listed; k++) {
     const uint32_t j = contacts[k][threadIdx.x];
     contactOf(j, prIn[j]);
@@ -277,26 +371,53 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
     if (doRadiusNext) out.z = pbActuateS(P, me.z, phase[s], dead[s], F.fa, F.fr, timeNext, dt);
     pbIntegrate(P, out.x, out.y, v.x, v.y, out.z, dt);
   }
-  prOut[s] = out;
-  velOut[s] = v;
-  if (ASUM) absA[s] = F.fa;
-  absR[s] = F.fr;
+  if (!WALK || alive) {
+    prOut[s] = out;
+    velOut[s] = v;
+    if (ASUM) absA[s] = F.fa;
+    absR[s] = F.fr;
+  }
 }
 
 }  // namespace
+
+namespace {
+template <bool PL, bool AS, bool WK>
+std::string streamNameT() {
+  auto b = [](bool v) { return std::string(v ? "true" : "false"); };
+  return "k_force_stream<" + b(PL) + ", " + b(AS) + ", " + b(WK) + ">" + pbKernelArgs(typeid(&k_force_stream<PL, AS, WK>).name());
+}
+}  // namespace
+
+// one place maps (payload, sums kept, walk) to an instantiation: the launch and the kernel's name
+#define PB_STREAM_FORMS(S, X)                                      \
+  do {                                                             \
+    const bool asum_ = attractionSumsKept(S), wk_ = pbStreamWalk(S); \
+    if ((S)->payload) {                                            \
+      if (asum_) { if (wk_) X(true, true, true); else X(true, true, false); }       \
+      else { if (wk_) X(true, false, true); else X(true, false, false); }           \
+    } else {                                                       \
+      if (asum_) { if (wk_) X(false, true, true); else X(false, true, false); }     \
+      else { if (wk_) X(false, false, true); else X(false, false, false); }         \
+    }                                                              \
+  } while (0)
+
+std::string pbForceStreamName(const pbSim *S) {
+  std::string name;
+#define PB_NAME(PL, AS, WK) name = streamNameT<PL, AS, WK>()
+  PB_STREAM_FORMS(S, PB_NAME);
+#undef PB_NAME
+  return name;
+}
 
 void pbLaunchForceStream(pbSim *S, bool fuse, int c, int o, float dt, float tNext, int doRadiusNext) {
   const uint32_t tiles = cdiv(S->n, TILE);
   const uint32_t perXcd = tiles >= 64u ? cdiv(tiles, 8u) : 0u;
   const dim3 grid(perXcd ? perXcd * 8u : tiles, S->nsims);
-  const bool asum = attractionSumsKept(S);
-#define PB_STREAM(PL, AS)                                                                                   \
-  hipLaunchKernelGGL((k_force_stream<PL, AS>), grid, dim3(TILE), 0, S->stream, S->dP, S->pr[c], S->vel[c], \
-                     S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c],     \
+#define PB_STREAM(PL, AS, WK)                                                                                   \
+  hipLaunchKernelGGL((k_force_stream<PL, AS, WK>), grid, dim3(TILE), 0, S->stream, S->dP, S->pr[c], S->vel[c], \
+                     S->pr[o], S->vel[o], S->phase[c], S->dead[c], S->absA[c], S->absR[c], S->orig[c],         \
                      S->cellS, S->n, dt, tNext, doRadiusNext, perXcd, (int)fuse)
-  if (S->payload && asum) PB_STREAM(true, true);
-  else if (S->payload) PB_STREAM(true, false);
-  else if (asum) PB_STREAM(false, true);
-  else PB_STREAM(false, false);
+  PB_STREAM_FORMS(S, PB_STREAM);
 #undef PB_STREAM
 }

@@ -118,7 +118,8 @@ class Timings(C.Structure):
     _fields_ = [("wall_s", C.c_double), ("placement_cpu_s", C.c_double), ("placement_wait_s", C.c_double),
                 ("upload_s", C.c_double), ("device_s", C.c_double), ("sub_batches", C.c_int), ("sub_batch", C.c_int),
                 ("host_threads", C.c_int), ("pinned", C.c_int), ("numa_node", C.c_int),
-                ("placement_thread_wall_s", C.c_double), ("lanes", C.c_int)]
+                ("placement_thread_wall_s", C.c_double), ("lanes", C.c_int), ("placements_run", C.c_int),
+                ("placements_shared", C.c_int)]
 
 
 class HostResources(C.Structure):
@@ -158,6 +159,8 @@ def _pipeline_lib():
                                         C.POINTER(Timings)]
     L.pbEnsemblePipelineRun.restype = C.c_long
     L.pbEnsemblePipelineDestroy.argtypes = [C.c_void_p]
+    L.pbEnsemblePipelinePlacementCounts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pbEnsemblePipelinePlacementCounts.restype = None
     L.pbEnsemblePipelineNumBots.argtypes = [C.c_void_p]
     L.pbEnsemblePipelineNumBots.restype = C.c_uint
     L.pbEnsemblePipelineGetState.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -239,6 +242,12 @@ class PipelinedEnsemble:
         """producer threads this pipeline started"""
         self._L.pbEnsemblePipelineHostThreads.argtypes = [C.c_void_p]
         return int(self._L.pbEnsemblePipelineHostThreads(self._h)) if self._h else 0
+
+    def placement_counts(self):
+        """(placements computed, members that took a copy of another member's placement) so far."""
+        run, shared = C.c_int(0), C.c_int(0)
+        self._L.pbEnsemblePipelinePlacementCounts(self._h, C.byref(run), C.byref(shared))
+        return run.value, shared.value
 
     def dry_run(self, dwell_ms=0):
         """CPU-only: the pipeline's consumer without a device.  Returns (checksums[m] of the placed members,

@@ -15,7 +15,7 @@ import time
 import numpy as np
 import pytest
 
-from test_bench_multirank import one_json_line, run_bench
+from test_bench_multirank import check_headline_line, one_json_line, run_bench, run_legs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "particlerobotsimulations_amd", "bin", "particlebot_ensemble")
@@ -35,8 +35,8 @@ def fake_quota(tmp_path, cpus=16):
 def eight_rank_configs3(tmp_path_factory):
     env = fake_quota(tmp_path_factory.mktemp("q"))
     t0 = time.time()
-    d = one_json_line(run_bench("--gpus", "8", "--workload", "ensemble4", "--members-total", "256", "--e2e-steps", "100",
-                                "--steps", "20", "--dry-run-device", env=env, timeout=900))
+    d = one_json_line(run_legs("--gpus", "8", "--workload", "ensemble4", "--members-total", "256", "--e2e-steps", "100",
+                               "--steps", "20", "--dry-run-device", env=env, timeout=900))
     d["_wall"] = time.time() - t0
     return d
 
@@ -65,8 +65,8 @@ def test_eight_rank_configs3_line(eight_rank_configs3):
 def test_eight_rank_gather_puts_every_member_in_its_place(eight_rank_configs3, tmp_path):
     """The same 256 + 256 members on ONE rank: the rows rank 0 assembled from eight blocks are the one-rank rows,
     member for member."""
-    one = one_json_line(run_bench("--gpus", "1", "--workload", "ensemble4", "--members-total", "256", "--e2e-steps", "100",
-                                  "--steps", "20", "--dry-run-device", env=fake_quota(tmp_path), timeout=900))
+    one = one_json_line(run_legs("--gpus", "1", "--workload", "ensemble4", "--members-total", "256", "--e2e-steps", "100",
+                                 "--steps", "20", "--dry-run-device", env=fake_quota(tmp_path), timeout=900))
     assert one["n_gpus"] == 1 and one["config"]["members_per_rank"] == [512]
     for key in ("last_rows_time_comx_comy_dist",):
         a, b = np.array(eight_rank_configs3["end_to_end"][key]), np.array(one["end_to_end"][key])
@@ -82,8 +82,8 @@ def test_eight_rank_gather_puts_every_member_in_its_place(eight_rank_configs3, t
 def test_eight_rank_configs4_line(tmp_path):
     """--workload ensemble5 on eight ranks, two 10^5-bot members per GPU (placed for real by one producer per rank)."""
     t0 = time.time()
-    d = one_json_line(run_bench("--gpus", "8", "--workload", "ensemble5", "--members-per-gpu", "2", "--e2e-steps", "20",
-                                "--steps", "10", "--dry-run-device", env=fake_quota(tmp_path), timeout=1200))
+    d = one_json_line(run_legs("--gpus", "8", "--workload", "ensemble5", "--members-per-gpu", "2", "--e2e-steps", "20",
+                               "--steps", "10", "--dry-run-device", env=fake_quota(tmp_path), timeout=1200))
     assert d["dry_run"] is True and d["n_gpus"] == 8 and d["scaling"] == "weak"
     assert d["config"]["members_per_rank"] == [2] * 8 and d["config"]["bots_per_member"] == [100000]
     assert d["end_to_end"]["rows_gathered"] == [[16, 3, 4]] and d["end_to_end"]["members_total"] == 16
@@ -92,6 +92,19 @@ def test_eight_rank_configs4_line(tmp_path):
     # rank 0's pipeline: its share of the host minus the thread that drives the device, at most one per member
     assert tm["host_threads"] == min(2, max(1, d["host"]["host_threads"] - 1))
     assert time.time() - t0 < 180
+
+
+def test_eight_rank_headline_line_is_small_and_names_eight_devices(tmp_path):
+    """The driver's SCALE form of bench.py on eight ranks: the line obeys the 4 KB limit, the process group reports
+    eight ranks, and every rank sits on its own LOCAL_RANK."""
+    p = run_bench("--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-run-device", "--e2e-steps", "50", "--detail",
+                  str(tmp_path / "d.json"), env=fake_quota(tmp_path), timeout=900)
+    d = check_headline_line(p, 8)
+    c = d["collective"]
+    assert c["ranks"] == 8 and sorted(x[0] for x in c["local_rank_device"]) == list(range(8))
+    assert d["ensemble"]["members_total"] == 512 and d["ensemble"]["rows_gathered"] == [[256, 3, 4], [256, 3, 4]]
+    long = json.loads((tmp_path / "d.json").read_text())
+    assert len(long["summaries_time_comx_comy"]) == 8
 
 
 def test_cxx_runner_id_exchange_world_size_8_with_a_stray():

@@ -109,6 +109,7 @@ def test_ensemble_header_symbols_are_exported_by_the_host_library():
                      "pbEnsembleAssemble", "pbEnsemblePipelineCreate", "pbEnsemblePipelineCreateCheckpointed",
                      "pbEnsemblePipelineRun", "pbEnsemblePipelineDestroy", "pbEnsemblePipelineNumBots",
                      "pbEnsemblePipelineGetState", "pbEnsemblePipelineDryRun", "pbEnsemblePipelineHostThreads", "pbEnsemblePipelineAutoSubBatch", "pbEnsemblePipelineSetLanes", "pbEnsemblePipelineSetCsvDir",
+                     "pbEnsemblePipelinePlacementCounts",
                      "pbHostGetResources", "pbHostParseCpuList"}
     L = host.lib()
     for n in names:

@@ -116,3 +116,90 @@ def test_members_of_a_batch_must_agree_on_the_force_kernel(capfd):
     with pytest.raises(RuntimeError):
         LocalEnsemble(CFG, ["seed\n1\npb_rng\ncurand", "seed\n2"], {"nCells": "40"})
     assert "must agree on pb_force_variant and pb_rng" in capfd.readouterr().err
+
+
+# ---- one placement per distinct blob ---------------------------------------------------------------
+def _sweep(order, seeds=4, fractions=6):
+    """A Cartesian sweep of nDead under a few seeds, seed-fastest or fraction-fastest (both orders occur: bench's
+    configs[4] leg, `particlebot_ensemble --cartesian`)."""
+    out = []
+    for k in range(seeds * fractions):
+        s, f = (k % seeds, k // seeds) if order == "seed-fastest" else (k // fractions, k % fractions)
+        out.append(f"seed\n{2000 + s}\nnDead\n{3 + 7 * f}")
+    return out
+
+
+def _dry_sweep(members, sub, threads, share=True, common=None):
+    from particlerobotsimulations_amd.ensemble import PipelinedEnsemble
+    old = os.environ.get("PB_SHARE_PLACEMENTS")
+    os.environ["PB_SHARE_PLACEMENTS"] = "1" if share else "0"
+    try:
+        p = PipelinedEnsemble(CFG, members, common or {"nCells": "400"}, sub_batch=sub, host_threads=threads)
+        sums, _ = p.dry_run(0)
+        counts = p.placement_counts()
+        p.close()
+    finally:
+        if old is None:
+            del os.environ["PB_SHARE_PLACEMENTS"]
+        else:
+            os.environ["PB_SHARE_PLACEMENTS"] = old
+    return sums, counts
+
+
+@pytest.mark.parametrize("order", ["seed-fastest", "fraction-fastest"])
+def test_members_of_one_seed_share_one_placement_and_stay_bit_identical(order):
+    """24 members = 4 seeds x 6 dead fractions: 4 placements are computed, 20 members take a copy of the placed state
+    AND of the private generator's state after it (the dead draw continues that stream, particlebot.cpp:178-194) --
+    and every member's placed state + dead set is what it is when each member places for itself."""
+    members = _sweep(order)
+    alone, c0 = _dry_sweep(members, 5, 3, share=False)
+    assert c0 == (24, 0)
+    assert len(set(alone.tolist())) == 24          # same blob, different dead sets: all different
+    for sub, threads in ((5, 3), (0, 1), (24, 8), (1, 2), (7, 5)):
+        sums, counts = _dry_sweep(members, sub, threads)
+        assert np.array_equal(sums, alone), (order, sub, threads)
+        # (a group placed AHEAD by an idle producer is copied by all its members, its first one included: 20 ... 23)
+        assert counts[0] == 4 and 20 <= counts[1] <= 23, (order, sub, threads, counts)
+
+
+def test_shared_placement_members_are_the_oracles(orc):
+    """Members that TOOK a placement, against the oracle placing and drawing each of them from scratch."""
+    members = _sweep("fraction-fastest", seeds=2, fractions=3)
+    sums, counts = _dry_sweep(members, 2, 2)
+    assert counts[0] == 2 and 4 <= counts[1] <= 5
+
+    def fnv(*arrays):
+        h = 1469598103934665603
+        for a in arrays:
+            for b in np.ascontiguousarray(a).view(np.uint8).reshape(-1).tolist():
+                h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    for k in range(6):
+        s, f = k // 3, k % 3
+        P = orc.load_cfg(CFG, nCells=400, seed=2000 + s, nDead=3 + 7 * f)
+        placed = orc.Sim(P, reset=True)
+        pos, rad = placed.get("pos"), placed.get("rad")
+        placed.run(1)
+        dead = placed.get("dead").astype(np.int32)
+        assert dead.sum() == 3 + 7 * f and int(sums[k]) == fnv(pos, rad, dead), k
+        placed.close()
+
+
+def test_what_is_and_is_not_shared():
+    """The key is what the placement READS: members that differ in light position or nDead >= 0 share; members that
+    differ in seed, size, radius or payload mode (nDead == -1: the last bot is the payload, placed left of the blob)
+    do not."""
+    base = "seed\n3000\nnDead\n4"
+    same = [base, "seed\n3000\nnDead\n9", "seed\n3000\nnDead\n4\nlight_x\n-7", "seed\n3000\nnDead\n0\ntime_to_dead\n3"]
+    _, counts = _dry_sweep(same, 0, 2)
+    assert counts == (1, 3)
+    differ = [base, "seed\n3001\nnDead\n4", "seed\n3000\nnDead\n4\nnCells\n401", "seed\n3000\nnDead\n-1",
+              "seed\n3000\nnDead\n4\nmin_radius\n0.08"]
+    sums, counts = _dry_sweep(differ, 0, 2)
+    assert counts == (5, 0) and len(set(sums.tolist())) == 5
+    # a unique member among shared ones is placed on its own
+    mixed = [base, "seed\n3005\nnDead\n4", "seed\n3000\nnDead\n6"]
+    sums, counts = _dry_sweep(mixed, 0, 3)
+    assert counts[0] == 2 and counts[1] in (1, 2)
+    alone, _ = _dry_sweep(mixed, 0, 3, share=False)
+    assert np.array_equal(sums, alone)

@@ -63,9 +63,9 @@ def test_bench_headline_workload_matches_oracle(orc):
         assert (a.x, a.y) == (b.x, b.y), name
     gsim = bench.make_sim(pb, n, bench.LATTICE_PITCH, seed=1)
     assert gsim.config()["force_variant"] == 2 and gsim.config()["lanes_per_bot"] == 1
-    # ... and the line's `both_sums` leg, the kernel `roofline.frac` is priced on (everything collideD writes)
-    gboth = bench.make_sim(pb, n, bench.LATTICE_PITCH, seed=1)
-    gboth.set_force_sums(1)
+    # ... and the HEADLINE form since round 6 (`value`, `roofline`: both magnitude sums, everything collideD writes);
+    # gsim above is the line's `default_form`
+    gboth = bench.make_sim(pb, n, bench.LATTICE_PITCH, seed=1, force_sums=1)
     assert gboth.config()["attraction_sums"] == 1 and gboth.config()["dead_sum_form"] == 0
     orc.lib().orc_set_num_threads(orc.usable_cpus())
     osim = orc.Sim(P, reset=True, hex=True)

@@ -1,5 +1,5 @@
-"""bench.py's output contract (one JSON line, the keys the driver and the judge read), exercised on
-a small arena so that it takes seconds."""
+"""bench.py's output contract (ONE JSON line under 4 KB with the keys the driver and the judge read; one kernel per
+headline) and tools/bench_legs.py's (every other leg, one long line), exercised on small arenas so that it takes seconds."""
 import json
 import os
 import subprocess
@@ -9,10 +9,95 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LEGS = os.path.join(ROOT, "tools", "bench_legs.py")
 
 
-def test_bench_prints_one_json_line_with_the_contract_keys():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bots", "200000", "--steps", "60",
+def test_headline_line_is_small_and_describes_one_kernel(tmp_path):
+    """`python bench.py`: value, ms_per_step and roofline are the SAME K launches of the both-sums kernel (everything
+    collideD writes, impl.cuh:828-830); the default (dead-sum) form, the CPU baseline and configs[3] ride along; the
+    line is under 4 KB and the long record is in the --detail file."""
+    n, k = 200000, 60
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bots", str(n), "--steps", str(k), "--warmup",
+                          "20", "--cpu-seconds", "1", "--e2e-steps", "1500", "--detail", str(tmp_path / "d.json")],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0].encode()) + 1 < 4096, (len(lines), len(lines[0]))
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "default_form", "ensemble", "detail"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == k and d["warmup"] == 20 and d["higher_is_better"] is True
+    assert d["unit"] == "particle-steps/s" and d["dtype"] == "f32" and d["vs_baseline"] is None and d["collective"] is None
+    c = d["config"]
+    assert "workload" in c and "model" not in c and len(c["workload"]) <= 200 and c["bots_per_gpu"] == n
+    assert c["attraction_sums"] == 1 and c["force_variant"] == 2 and c["lanes_per_bot"] == 1
+    r = d["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["kernel"] == "k_force<false, true, 1, 1, false, true>" and r["launches"] == k
+    assert r["alg_bytes_per_launch"] == 64.0 * n
+    # one kernel per headline: every figure recomputes from the same K launches
+    assert abs(r["avg_launch_us"] * k - d["device_ms_timed_region"] * 1e3) < 1e-6 * d["device_ms_timed_region"] * 1e3
+    assert abs(r["achieved"] - 64.0 * n / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-9
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(d["value"] - n * k / (d["ms_per_step"] * k * 1e-3)) / d["value"] < 1e-6
+    # wall clock of the K steps >= their device time, and close to it: 64 * value / peak ~ frac
+    assert d["ms_per_step"] * k >= d["device_ms_timed_region"] * 0.999
+    assert 0.85 * r["frac"] < 64.0 * d["value"] / 8e12 <= r["frac"] * 1.001
+    assert r["long"]["steps"] * r["long"]["avg_launch_us"] * 1e-3 >= 90.0 and r["long"]["frac"] > 0   # (K steps were < 50 ms)
+    assert r["traffic"] is None and r["profile"]["dropped"] == "not 10^6 bots"   # the committed counters are 10^6-bot ones
+    f = d["default_form"]
+    assert f["attraction_sums"] == 0 and f["kernel"] == "k_force<false, true, 1, 1, false, false>"
+    assert abs(f["frac_at_56B"] - 56.0 * f["value"] / 8e12) < 1e-12 and f["value"] > d["value"] * 0.95
+    b = d["cpu_baseline"]
+    assert b["kind"] == "port" and b["cores"] >= 1 and b["value"] > 0 and b["value_1_thread"] > 0 and "sample" in b
+    e = d["ensemble"]
+    # (1 500 steps: rows at t = 0, 0.01, 6 and 12)
+    assert e["members_total"] == 512 and e["steps_per_member"] == 1500 and e["rows_gathered"] == [[256, 4, 4], [256, 4, 4]]
+    long = json.loads((tmp_path / "d.json").read_text())
+    assert long["line"] == d and long["headline"]["prewarm"]["ms"] >= 100.0 and "glibc" in long["host"]
+    assert long["default_form"]["timed"]["device_prewarm_ms"] >= 100.0
+
+
+def test_headline_line_through_rccl_with_one_rank(tmp_path):
+    """--force-dist: the N > 1 code path on one GPU -- RCCL communicator, barriers, MAX all-reduce, gather of the arena
+    summaries and of the configs[3] rows -- and `collective` says what the communicator saw."""
+    raw = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bots", "150000", "--steps", "40", "--warmup",
+                          "10", "--force-dist", "--no-cpu-baseline", "--e2e-steps", "300", "--detail", str(tmp_path / "d.json")],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert raw.returncode == 0, raw.stderr[-2000:]
+    lines = [l for l in raw.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:3]      # ONE line on stdout: RCCL's version banner goes to stderr
+    d = json.loads(lines[0])
+    assert d["collective"] == {"backend": "rccl", "torch_backend": "nccl", "ranks": 1, "local_rank_device": [[0, 0]]}
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["ensemble"]["rows_gathered"] == [[256, 2, 4], [256, 2, 4]]
+    long = json.loads((tmp_path / "d.json").read_text())
+    assert len(long["summaries_time_comx_comy"]) == 1
+
+
+def test_profile_counters_are_quoted_only_for_the_loaded_kernel():
+    """At 10^6 bots the line quotes the committed PMC profile (profiles/latest_traffic_both_sums.json) only if its
+    kernel signature is the loaded library's; the detail record says which build the profile was taken on."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "20",
+                          "--no-cpu-baseline", "--no-ensemble", "--detail", ""], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    r = d["roofline"]
+    prof = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic_both_sums.json")))
+    import particlerobotsimulations_amd as pb
+    sig = [pb.force_form_kernel_name(i) for i, f in enumerate(pb.force_forms())
+           if f == {"flat": 1, "lanes_per_bot": 1, "attraction_sums": 1, "offsets64": 0}][0]
+    if prof.get("kernel_signature") == sig:
+        assert r["traffic"] == prof["hbm_bytes_per_launch"] and 0.3 < r["valu_frac_of_datasheet"] < 1.0
+        assert r["profile"]["name"] == prof["profile"] and isinstance(r["profile"]["sources_match"], bool)
+        assert 0.8 < r["traffic"] / r["alg_bytes_per_launch"] < 1.5      # no wasted re-reads
+    else:
+        assert r["traffic"] is None and r["valu_frac_of_datasheet"] is None and "dropped" in r["profile"]
+
+
+def test_legs_line_carries_every_leg():
+    out = subprocess.run([sys.executable, LEGS, "--bots", "200000", "--steps", "60",
                           "--warmup", "20", "--cpu-seconds", "1", "--e2e-steps", "1500"], capture_output=True, text=True,
                          timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -76,7 +161,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 
 
 def _bench(*args):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, LEGS, *args], capture_output=True, text=True,
                          timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
@@ -114,7 +199,10 @@ def test_ensemble5_workload_line():
     assert d["config"]["bots_per_member"] == [100000] and d["config"]["members_per_gpu"] == 2
     g = d["summary_rows_gathered"]   # rows at t = 0 and 0.01, more if the >= 100 ms region reached t = 6
     assert d["value"] > 1e8 and len(g) == 1 and g[0][0] == 2 and g[0][1] >= 2 and g[0][2] == 4
-    assert d["end_to_end"]["steps_per_member"] == 80 and d["end_to_end"]["pipeline_rank0"][0]["placement_cpu_s"] > 0.5
+    tm = d["end_to_end"]["pipeline_rank0"][0]
+    # the two members are two dead fractions of ONE seed: one placement (~0.27 CPU-s at 10^5 bots), one copy
+    assert d["end_to_end"]["steps_per_member"] == 80 and tm["placement_cpu_s"] > 0.1
+    assert tm["placements_run"] == 1 and tm["placements_shared"] == 1
 
 
 def test_ensemble_strong_form_members_total():
@@ -129,7 +217,7 @@ def test_arena_line_through_rccl_with_one_rank_and_gpus_flag_is_checked():
     """The N > 1 code path of the default workload on one GPU: --force-dist initialises RCCL (world 1),
     runs the barrier / max-over-ranks all_reduce / all_gather of the arena summaries.  And `--gpus 2`
     without a launcher on a one-GPU box refuses loudly instead of silently running one arena."""
-    raw = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bots", "150000", "--steps", "40", "--warmup",
+    raw = subprocess.run([sys.executable, LEGS, "--bots", "150000", "--steps", "40", "--warmup",
                           "10", "--force-dist", "--no-cpu-baseline", "--no-survey-literal", "--no-streamlined",
                           "--no-large-arena", "--no-blob", "--e2e-steps", "300"], capture_output=True, text=True,
                          timeout=900, cwd=ROOT)
@@ -151,7 +239,7 @@ def test_arena_line_through_rccl_with_one_rank_and_gpus_flag_is_checked():
 
 
 def test_force_sums_flag_profiles_the_both_sums_kernel_as_the_arena():
-    """`bench.py --force-sums 1` (what tools/profile.sh runs for profiles/r5_both_sums.*): the arena itself keeps both
+    """`tools/bench_legs.py --force-sums 1` (what tools/profile.sh runs for profiles/r6_both_sums.*): the arena itself keeps both
     magnitude sums, so that kernel is the one under the profiler; the line says it is not the headline."""
     d = _bench("--bots", "100000", "--steps", "40", "--warmup", "10", "--force-sums", "1", "--no-cpu-baseline",
                "--no-survey-literal", "--no-streamlined", "--no-large-arena", "--no-clock", "--no-blob", "--no-ensemble-leg",

@@ -303,7 +303,23 @@ def test_csv_dir_never_writes_a_silently_shortened_file(tmp_path, capfd):
     with pytest.raises(RuntimeError):
         p.run()
     p.close()
-    assert "a CSV row is due" in capfd.readouterr().err
+    # (refused BEFORE the first step -- the row count follows from dt, dump_interval and max_time -- not
+    #  when row 4 falls due, possibly hours into the run)
+    assert "nothing was stepped" in capfd.readouterr().err
+    # the same without --csv-dir: rows past max_rows used to be dropped silently
+    p = ensemble.PipelinedEnsemble(EX("example.cfg"), members, common, sub_batch=0, host_threads=2, max_rows=6)
+    with pytest.raises(RuntimeError):
+        p.run()
+    p.close()
+    assert "more than 6 summary rows" in capfd.readouterr().err
+    p = ensemble.PipelinedEnsemble(EX("example.cfg"), members, common, sub_batch=0, host_threads=2, max_rows=7)
+    assert p.run() > 0 and p.rows.shape[1] == 7          # rows at 0, 0.01, 6, 12, 18, 24, 30.0x: exactly what fits
+    p.close()
+    # a run bounded by max_steps needs only the rows of those steps (1 500 steps: t = 0, 0.01, 6, 12)
+    p = ensemble.PipelinedEnsemble(EX("example.cfg"), members, dict(common, max_time="1e9"), sub_batch=0, host_threads=2,
+                                   max_rows=4)
+    assert p.run(1500) == 1500 and p.rows.shape[1] == 4
+    p.close()
     d2 = tmp_path / "whole"
     d2.mkdir()
     p = ensemble.PipelinedEnsemble(EX("example.cfg"), members, common, sub_batch=0, host_threads=2, max_rows=16,

@@ -124,3 +124,30 @@ def test_force_variant_key_reaches_the_batched_engine(orc):
         d = np.linalg.norm(a["pos"].astype(np.float64) - b["pos"], axis=1)
         # (60 un-resynchronised steps of a chaotic blob: most bots still agree exactly, the tail has started to drift)
         assert np.median(d) <= 1e-7 and np.quantile(d, 0.99) <= 1e-3 and d.max() <= 60 * 2.5e-4
+
+
+def test_members_that_share_a_placement_equal_their_stand_alone_oracle_runs(orc):
+    """a Cartesian dead-fraction sweep (3 fractions x 2 seeds, the dead set drawn at t = 0 for one
+    seed's worth of configuration and at t = 2 for the other) places each seed's blob ONCE; the members that took a copy
+    of the placement -- and of the private generator's state after it -- end bit-equal to the oracle placing, drawing
+    and stepping each member from scratch, rows included."""
+    from particlerobotsimulations_amd import ensemble
+    cfg = EX("example_dead_cells.cfg")
+    for ttd in ("0", "2"):
+        common = {"nCells": "600", "max_time": "6.2", "dump_interval": "6", "time_to_dead": ttd}
+        spec = [(seed, nd) for seed in (4100, 4101) for nd in (0, 90, 240)]
+        members = [f"seed\n{s}\nnDead\n{nd}" for s, nd in spec]
+        p = ensemble.PipelinedEnsemble(cfg, members, common, sub_batch=4, host_threads=3, keep_final_states=True)
+        steps = p.run()
+        tm, rows, states = p.timings, p.rows, p.final_states()
+        p.close()
+        assert steps in (620, 621) and tm["placements_run"] == 2 and 4 <= tm["placements_shared"] <= 5
+        for k, (s, nd) in enumerate(spec):
+            orows, osim = oracle_member(orc, cfg, dict(nCells=600, seed=s, nDead=nd, max_time=6.2, dump_interval=6.0,
+                                                       time_to_dead=float(ttd)), 6.0)
+            assert np.array_equal(orows[:, 0].astype(np.float32), rows[k, :, 0]), (ttd, k)
+            assert np.abs(orows[:, 1:] - rows[k, :, 1:]).max() < 2e-6
+            for key in ("pos", "vel", "rad"):
+                assert_bit_equal(states[k][key], osim.get(key), f"time_to_dead {ttd} member {k} (seed {s}, nDead {nd}): {key}")
+            assert int(osim.get("dead").sum()) == nd
+            osim.close()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel trace + three separate PMC passes of the
-# bench workload, raw output under gpurun_out/prof_<tag>/, then a distilled summary next to it.
+# arena workload of tools/bench_legs.py, raw output under gpurun_out/prof_<tag>/, then a distilled summary next to it.
 # usage: tools/profile.sh <tag> [bench args...]      (PB_PROFILE_VARIANT=3: profile the streamlined kernel)
 set -u
 TAG=${1:-run}; shift || true
@@ -11,7 +11,7 @@ export PB_PROFILE_ARGS="$ARGS"   # summarize_profile.py quotes the command in tr
 export TMPDIR=/tmp
 run() { # name, rocprof flags...
   local name=$1; shift
-  timeout 600 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o "$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1
+  timeout 600 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o "$name" -- python3 tools/bench_legs.py $ARGS > "$OUT/$name.log" 2>&1
   echo "$name rc=$?" >> "$OUT/status.txt"
 }
 run trace --kernel-trace --stats
@@ -24,7 +24,7 @@ run pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 [ -x tools/valu_rate ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/valu_rate.hip -o tools/valu_rate
 tools/valu_rate > "$OUT/valu_rate.txt" 2>&1
 # the same command un-profiled: kernel time at un-profiled clocks
-python3 bench.py $ARGS 2>/dev/null | tail -1 > "$OUT/bench_unprofiled.json"
+python3 tools/bench_legs.py $ARGS 2>/dev/null | tail -1 > "$OUT/bench_unprofiled.json"
 python3 tools/summarize_profile.py "$OUT" "$OUT/traffic.json" > "$OUT/summary.md" 2>"$OUT/summarize.err"
 cat "$OUT/summary.md"
 # SURVEY 8(d) caveat 2: the same kernel at 8 x 10^6 bots (544 MB of state, beyond the 256 MiB Infinity
@@ -36,7 +36,7 @@ if [ "${PB_PROFILE_LARGE:-1}" = "1" ]; then
   run trace --kernel-trace --stats
   run pmc_fetch --pmc FETCH_SIZE
   run pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-  python3 bench.py $ARGS 2>/dev/null | tail -1 > "$OUT/bench_unprofiled.json"
+  python3 tools/bench_legs.py $ARGS 2>/dev/null | tail -1 > "$OUT/bench_unprofiled.json"
   python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
   cat "$OUT/summary.md"
 fi

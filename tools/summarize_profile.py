@@ -20,6 +20,29 @@ def short(name):
     return name.strip()[:60]
 
 
+def signature(name):
+    """A kernel name as pbSimForceKernelName spells it: template arguments and argument types, no `void`, no
+    namespace, single spaces."""
+    for pre in ("void ", "(anonymous namespace)::"):
+        name = name.replace(pre, "")
+    return " ".join(name.split())
+
+
+FULL_NAMES = {}   # short name -> the trace's full Kernel_Name
+
+
+def build_stamp():
+    """lib/build_stamp.json of the libraries this profile ran (csrc/Makefile writes it): content hash of the force
+    kernels' sources + commit."""
+    import json
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        with open(os.path.join(here, "particlerobotsimulations_amd", "lib", "build_stamp.json")) as fh:
+            return json.load(fh)
+    except Exception:
+        return None
+
+
 def kernel_trace(root):
     rows = []
     for f in find(os.path.join(root, "trace"), "*kernel_trace.csv"):
@@ -30,6 +53,7 @@ def kernel_trace(root):
     meta = {}
     for r in rows:
         k = short(r["Kernel_Name"])
+        FULL_NAMES[k] = r["Kernel_Name"]
         agg[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         meta[k] = (r.get("VGPR_Count", "?"), r.get("SGPR_Count", "?"), r.get("LDS_Block_Size", "?"),
                    r.get("Grid_Size", r.get("Grid_Size_X", "?")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", "?")))
@@ -207,11 +231,13 @@ def main():
                                                        "ns_simple", "ns_trans", "trans_per_wave", "valu_rate_mhz",
                                                        "valu_rate_cycles")})
                 with open(traffic_json, "w") as fh:
-                    json.dump({**valu, "kernel": k, "profile": os.path.basename(root), "fetch_bytes_per_launch": fetch,
+                    json.dump({**valu, "kernel": k, "kernel_signature": signature(FULL_NAMES.get(k, k)),
+                               "build": build_stamp(), "calls": len(agg[k]),
+                               "profile": os.path.basename(root), "fetch_bytes_per_launch": fetch,
                                "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                                "avg_launch_us_profiled": avg_ns / 1e3,
                                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
-                                         "`python3 bench.py " + os.environ.get("PB_PROFILE_ARGS", "--steps 400 --warmup 100 --no-cpu-baseline "
+                                         "`python3 tools/bench_legs.py " + os.environ.get("PB_PROFILE_ARGS", "--steps 400 --warmup 100 --no-cpu-baseline "
                                          "--no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg") + "`; FETCH_SIZE x2 (gfx950 wide-read correction) "
                                          "x1024, WRITE_SIZE x1024 (MI355X_MICROARCH.md, HBM section)"}, fh)
             print(f"- derived: HBM-side traffic per launch = read {fetch/1e6:.1f} MB (FETCH_SIZE x2 x1024) + "
