@@ -223,6 +223,13 @@ int pbSimStep(pbSim *sim, float deltaTime, float sort_interval, int nsteps, int 
 /* Same, bracketed by HIP events on the simulation's stream; *elapsed_ms is device time. */
 int pbSimStepTimed(pbSim *sim, float deltaTime, float sort_interval, int nsteps, int *steps_done,
                    float *elapsed_ms);
+/* Same, and *wall_ms (if not NULL) = the HOST's clock over the region: from entry -- the caller has synchronised, the
+ * stream is idle -- through every launch to the return of a closing hipStreamSynchronize.  The host polls for the
+ * end of the region instead of sleeping on an interrupt, so for a region of a few milliseconds wall and device time
+ * differ only by the dispatch and completion latencies (~10 us; PB_TIMED_TRACE=1 prints where the host's time went).
+ * bench.py's `value` is over this clock, its `roofline` over *elapsed_ms, of the same launches. */
+int pbSimStepTimedWall(pbSim *sim, float deltaTime, float sort_interval, int nsteps, int *steps_done,
+                       float *elapsed_ms, double *wall_ms);
 int pbSimSynchronize(pbSim *sim);
 
 /* Centre of mass, reduced on the device in a fixed order (double accumulation). */

@@ -283,6 +283,14 @@ class Sim:
                                                C.byref(ms)), "pbSimStepTimed")
         return done.value, ms.value
 
+    def step_timed_wall(self, nsteps, dt=0.01, sort_interval=180.0):
+        """(steps done, device ms between HIP events, host wall ms from entry to the drained stream) of the same
+        launches (pbSimStepTimedWall): synchronise before calling."""
+        done, ms, wall = C.c_int(), C.c_float(), C.c_double()
+        _capi.check(_capi.lib().pbSimStepTimedWall(self._h, dt, sort_interval, int(nsteps), C.byref(done), C.byref(ms),
+                                                   C.byref(wall)), "pbSimStepTimedWall")
+        return done.value, ms.value, wall.value
+
     def synchronize(self):
         _capi.check(_capi.lib().pbSimSynchronize(self._h))
 

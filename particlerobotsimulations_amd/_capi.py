@@ -138,6 +138,7 @@ SYMBOLS = {
     "pbSimSetPhaseDraws": (_I, [_VP, _U]),
     "pbSimStep": (_I, [_VP, _F, _F, _I, C.POINTER(_I)]),
     "pbSimStepTimed": (_I, [_VP, _F, _F, _I, C.POINTER(_I), C.POINTER(_F)]),
+    "pbSimStepTimedWall": (_I, [_VP, _F, _F, _I, C.POINTER(_I), C.POINTER(_F), C.POINTER(C.c_double)]),
     "pbSimSynchronize": (_I, [_VP]),
     "pbSimCentroid": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pbSimGetStats": (_I, [_VP, C.POINTER(pbSimStats)]),

@@ -1078,6 +1078,11 @@ int pbSimStep(pbSim *S, float deltaTime, float sort_interval, int nsteps, int *s
 
 int pbSimStepTimed(pbSim *S, float deltaTime, float sort_interval, int nsteps, int *steps_done,
                    float *elapsed_ms) {
+  return pbSimStepTimedWall(S, deltaTime, sort_interval, nsteps, steps_done, elapsed_ms, nullptr);
+}
+
+int pbSimStepTimedWall(pbSim *S, float deltaTime, float sort_interval, int nsteps, int *steps_done,
+                       float *elapsed_ms, double *wall_ms) {
   if (!S || nsteps < 0) return PB_ERR_ARG;
   // PB_TIMED_TRACE=1 (diagnostic): where the host's time around a timed region goes, in microseconds from entry
   static const bool trace = [] { const char *v = getenv("PB_TIMED_TRACE"); return v && v[0] == '1'; }();
@@ -1104,6 +1109,12 @@ int pbSimStepTimed(pbSim *S, float deltaTime, float sort_interval, int nsteps, i
   }
   const double tDone = us();
   PB_TRY(hipEventSynchronize(S->ev1));
+  if (wall_ms) {
+    // the host's clock over the same region, closed by a stream synchronisation: entry (the stream idle, the caller
+    // having synchronised) -> every launch issued -> the stream drained
+    PB_TRY(hipStreamSynchronize(S->stream));
+    *wall_ms = us() * 1e-3;
+  }
   float ms = 0.0f;
   PB_TRY(hipEventElapsedTime(&ms, S->ev0, S->ev1));
   if (elapsed_ms) *elapsed_ms = ms;

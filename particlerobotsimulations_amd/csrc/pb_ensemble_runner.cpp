@@ -353,6 +353,14 @@ int main(int argc, char **argv) {
   FILE *const jsonOut = jsonFd >= 0 ? fdopen(jsonFd, "w") : stdout;
   ncclComm_t comm;
   CHECK_NCCL(ncclCommInitRank(&comm, world, id, rank));
+  // what the communicator itself says (the line reports it: "RCCL saw N ranks" is checkable from the output)
+  int commRanks = 0, commDevice = -1;
+  CHECK_NCCL(ncclCommCount(comm, &commRanks));
+  CHECK_NCCL(ncclCommCuDevice(comm, &commDevice));
+  if (commRanks != world) {
+    fprintf(stderr, "rank %d: the communicator has %d ranks, the launcher said %d\n", rank, commRanks, world);
+    return 1;
+  }
   hipStream_t stream;
   CHECK_HIP(hipStreamCreate(&stream));
 
@@ -478,14 +486,15 @@ int main(int argc, char **argv) {
            "\"pipeline_rank0\": {\"sub_batch\": %d, \"sub_batches\": %d, \"lanes\": %d, \"host_threads\": %d, \"placement_cpu_s\": %.4f, "
            "\"placement_wait_s\": %.4f, \"upload_s\": %.4f, \"device_s\": %.4f, \"pinned_to_gpu_numa_node\": %s, "
            "\"numa_node\": %d, \"bound\": \"%s\"}, \"host\": \"%s\", \"resumed\": %s, "
-           "\"collective\": \"ncclAllGather of %zu floats per rank (RCCL)\"}\n",
+           "\"collective\": {\"backend\": \"rccl\", \"ranks\": %d, \"rank0_device\": %d, \"placements_run_rank0\": %d, "
+           "\"what\": \"ncclAllGather of %zu floats per rank\"}}\n",
            cfgPath.c_str(), members, world, (int)hs[2], (long)hs[3], allRows, wall, members / wall,
            (double)members * hs[2] * hs[3] / wall, mean, sqrt(var > 0 ? var : 0), tm.sub_batch, tm.sub_batches,
            tm.lanes, tm.host_threads, tm.placement_cpu_s, tm.placement_wait_s, tm.upload_s, tm.device_s, tm.pinned ? "true" : "false",
            tm.numa_node,
            // host-bound: this rank's placement CPU-seconds over its producer threads exceed the device's time
            tm.placement_cpu_s / (tm.host_threads > 0 ? tm.host_threads : 1) > tm.device_s + tm.upload_s ? "host" : "device",
-           hostRule.c_str(), resume ? "true" : "false", block);
+           hostRule.c_str(), resume ? "true" : "false", commRanks, commDevice, tm.placements_run, block);
     fflush(jsonOut);
     if (!outPath.empty()) {
       FILE *f = fopen(outPath.c_str(), "wb");

@@ -26,10 +26,10 @@ namespace {
 #define PB_STREAM_NEAR 1e-7f  // a candidate this close to contact (or closer, or in contact) goes to the contact pass
 #endif
 #ifndef PB_STREAM_CAP
-#define PB_STREAM_CAP 12  // contacts per lane listed in LDS (further ones are evaluated in place)
-#endif
-#ifndef PB_STREAM_CAP_WALK
-#define PB_STREAM_CAP_WALK 10  // the same in the flattened-walk form: 10 KB + the 10 KB range queue = 8 workgroups per CU
+// contacts per lane listed in LDS (further ones are evaluated in place, i.e. summed earlier than the listed ones).  ONE
+// value for both walks, so that they agree bit for bit in pile-ups too (12 until round 6; 10 lets the flattened walk's
+// 10 KB range queue fit beside the 10 KB of lists at 8 workgroups per CU; a bot of a blob has ~6 contacts)
+#define PB_STREAM_CAP 10
 #endif
 #define PB_WALK_QUEUE 5  // queue entries per lane: ranges 1..4 of the compacted list + the sentinel
 
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(TILE) void k_force_stream(const PbDevParams *__rest
                                                        float *__restrict__ absR, const uint32_t *__restrict__ orig,
                                                        const uint32_t *__restrict__ cellSAll, uint32_t n, float dt,
                                                        float timeNext, int doRadiusNext, uint32_t perXcd, int fuse) {
-  constexpr int CAP = WALK ? PB_STREAM_CAP_WALK : PB_STREAM_CAP;
+  constexpr int CAP = PB_STREAM_CAP;
   // one block: the range queue of the flattened walk (uint2 columns) in front of the contact lists (column = lane:
   // conflict-free)
   constexpr int QW = WALK ? 2 * PB_WALK_QUEUE : 0;

@@ -151,6 +151,28 @@ def test_config5_slice_statistic_is_the_same_with_the_tolerance_kernel(tmp_path)
     assert np.abs(p_t - p_e).max() <= 5 * s_e.max(), (np.abs(p_t - p_e).max(), s_e.max())
 
 
+def test_cartesian_sweep_places_each_seed_once_and_members_are_the_oracles(tmp_path, orc):
+    """`particlebot_ensemble --sweep nDead ... --cartesian` (round 6): the swept values form a grid and every grid point
+    runs under each seed -- member k = grid point k mod G under seed seed0 + k / G, BASELINE configs[4]'s "64 points x
+    16 seeds" in small -- so the members of one seed share ONE placement (and the generator state after it); every
+    member still equals its own stand-alone oracle run."""
+    di, dead = 6.0, [0, 40, 150, 320]
+    sets = {"nCells": "2000", "light_x": "-9", "light_y": "0", "max_time": "6.1", "dump_interval": str(di)}
+    info, rows = run_ensemble(tmp_path, "example_dead_cells.cfg", 12, sets, sweep=("nDead", dead), extra=("--cartesian",),
+                              port="29453")
+    assert info["members"] == 12 and info["bots_per_member"] == 2000
+    assert info["collective"]["placements_run_rank0"] == 3           # three seeds, four dead fractions each
+    over_of = lambda k: dict(seed=1000 + k // 4, nDead=dead[k % 4], nCells=2000, light_x=-9.0, light_y=0.0)
+    # the same blob under the four fractions of a seed: identical at t = 0, apart afterwards
+    assert np.array_equal(rows[0, 0, 1:3], rows[3, 0, 1:3]) and not np.array_equal(rows[0, -1, 1:3], rows[3, -1, 1:3])
+    assert not np.array_equal(rows[0, 0, 1:3], rows[4, 0, 1:3])
+    for k in range(12):
+        orows, osim = oracle_member(orc, EX("example_dead_cells.cfg"), dict(over_of(k), max_time=6.1), di)
+        assert np.array_equal(orows[:, 0].astype(np.float32), rows[k, :, 0]), k
+        assert np.abs(orows[:, 1:] - rows[k, :, 1:]).max() < 2e-6, k
+        osim.close()
+
+
 def test_config5_whole_sweep_1024_members_reproduces_the_recorded_statistic(tmp_path, orc):
     """BASELINE configs[4] WHOLE under the driver's eyes (until now a builder soak): all 1 024
     members -- 64 dead fractions 0 ... 0.40 x 16 seeds of examples/example_dead_cells.cfg at 10^5 bots, light at
@@ -207,5 +229,8 @@ def test_config5_whole_sweep_1024_members_reproduces_the_recorded_statistic(tmp_
     if usable >= 16:
         assert pl["bound"] == "device", pl
     assert pl["lanes"] == 2 and pl["sub_batches"] >= 30
+    # what the communicator itself reported (ncclCommCount), and: 1 024 seeds = 1 024 placements, nothing shared
+    c = info["collective"]
+    assert c["backend"] == "rccl" and c["ranks"] == 1 and c["rank0_device"] == 0 and c["placements_run_rank0"] == 1024
     over_of = lambda k: dict(seed=seeds[k], nDead=dead[k % 64], nCells=100000, light_x=-40.0, light_y=0.0)
     replay_three_members(orc, np.random.default_rng(9), "example_dead_cells.cfg", members, over_of, di, rows)

@@ -1,9 +1,8 @@
 """The two neighbour walks of the streamlined kernel (force variant 3; csrc/pb_stream.hip, WALK).
 Row by row, the wave runs the longest row of its 64 lanes five times; flattened, every lane walks its own five ranges
-back to back and the wave runs its longest list.  Every bot meets the same candidates in the same order, so the two
-walks must agree BIT FOR BIT (as long as no bot has more contacts than the shorter contact list of the flattened form
-holds, 10: beyond that the overflowing contacts are summed in another order -- still the tolerance kernel's 1e-5).  The
-engine chooses per batch at each re-sort: flattened on the reference's kind of random blob, row by row on the bench
+back to back and the wave runs its longest list.  Every bot meets the same candidates in the same order (and both forms
+list the same 10 contacts per lane before evaluating further ones in place), so the two walks must agree BIT FOR BIT,
+pile-ups against a wall included.  The engine chooses per batch at each re-sort: flattened on the reference's kind of random blob, row by row on the bench
 lattice.  The kernel's parity with the oracle is tests/test_gpu_streamlined.py / test_gpu_fma_bracket.py, which run
 the automatic choice."""
 import os

@@ -15,7 +15,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import benchkit as bench  # noqa: E402  (the workload builders)
+from bench_legs import BlobPlacement  # noqa: E402
 
 
 def main():
@@ -39,7 +41,7 @@ def main():
     n = args.bots
     variants = args.variants.split(",")
     if args.lattice == "blob":   # the reference's kind of initial state: a random blob (pb_placement fastblob)
-        pos, _ = bench.BlobPlacement(n).get()
+        pos, _ = BlobPlacement(n).get()
     else:
         pos = (bench.square_lattice(n, args.pitch) if args.lattice == "square"
                else bench.hex_lattice(n, np.float32(args.pitch)))
@@ -47,14 +49,20 @@ def main():
     for v in variants:
         sp, keep = bench.workload_params(n, seed=1)
         s = pb.Sim(sp, wall_half=240.0, keepalive=keep)
-        # "2" = force variant 2; "2s1" = variant 2 with both magnitude sums kept (pbSimSetForceSums 1)
+        # "2" = force variant 2; "2s1" = variant 2 with both magnitude sums kept (pbSimSetForceSums 1); "3w0" / "3w1" =
+        # the streamlined kernel with its neighbour walk pinned row by row / flattened (pbSimSetStreamWalk; "3": automatic)
+        walk = None
+        if "w" in v:
+            v, walk = v.split("w")[0], int(v.split("w")[1])
         s.set_force_variant(int(v.split("s")[0]))
         if "s" in v:
             s.set_force_sums(int(v.split("s")[1]))
+        if walk is not None:
+            s.set_stream_walk(walk)
         s.set_state(pos=pos, vel=np.zeros((n, 2), np.float32), rad=np.full(n, 0.0775, np.float32),
                     phase=np.zeros(n, np.float32), dead=np.zeros(n, np.int32))
         s.step(args.skip)
-        sims[v] = s
+        sims[v if walk is None else f"{v}w{walk}"] = s
     times = {v: [] for v in variants}
     for r in range(args.rounds):
         for v in variants:

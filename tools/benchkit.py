@@ -81,6 +81,9 @@ class _DrySim:
     def step_timed(self, k, *a):
         return self.step(k), 0.08 * k
 
+    def step_timed_wall(self, k, *a):
+        return self.step(k), 0.08 * k, 0.0805 * k
+
     def synchronize(self):
         pass
 

@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 export PB_ALLOW_ENV_OVERRIDES=1
 for m in 32 8 64; do for rep in 1 2; do for x in 0 1; do
-  PB_XCD_MEMBERS=$x python bench.py --workload ensemble4 --members-per-gpu $m --steps 8000 --warmup 200 --no-cpu-baseline --no-end-to-end 2>/dev/null | python -c "
+  PB_XCD_MEMBERS=$x python tools/bench_legs.py --workload ensemble4 --members-per-gpu $m --steps 8000 --warmup 200 --no-cpu-baseline --no-end-to-end 2>/dev/null | python -c "
 import json,sys,hashlib
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 h=d['steps'] + d.get('steps_long', 0)

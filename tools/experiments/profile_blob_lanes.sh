@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/prof_blob
 for v in 2 3; do
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d gpurun_out/prof_blob/v$v -o pmc -- python3 bench.py --workload ensemble5 --members-per-gpu 16 --force-variant $v --steps 200 --warmup 20 --no-cpu-baseline --no-end-to-end > gpurun_out/prof_blob/v$v.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d gpurun_out/prof_blob/v$v -o pmc -- python3 tools/bench_legs.py --workload ensemble5 --members-per-gpu 16 --force-variant $v --steps 200 --warmup 20 --no-cpu-baseline --no-end-to-end > gpurun_out/prof_blob/v$v.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 agg=collections.defaultdict(lambda: collections.defaultdict(list))

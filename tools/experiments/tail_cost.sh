@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=gpurun_out/tail; mkdir -p $OUT
 ARGS="--bots 200000 --pitch 1.0 --steps 400 --warmup 50 --prewarm-ms 0 --no-cpu-baseline --no-survey-literal --no-streamlined --no-large-arena --no-clock --no-blob --no-ensemble-leg --no-both-sums --no-host-round-trip"
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc -o pmc -- python3 bench.py $ARGS > $OUT/log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc -o pmc -- python3 tools/bench_legs.py $ARGS > $OUT/log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
