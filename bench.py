@@ -4,7 +4,7 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
 Workload (BASELINE.json configs[2]): 10^6 oscillating bots on a square lattice (pitch 0.155:
-jammed and dense for the whole run, ~57 candidate pairs per bot; DESIGN.md section 6 says why not the hexagonal one) in
+jammed and dense for the whole run, ~57 candidate pairs per bot; DESIGN.md section 5 says why not the hexagonal one) in
 the generalised arena (2048^2 grid, walls +-240), one light at (-230, 0), phase_std 0, dt 0.01, sort_interval 180.
 A "step" is one timestep of the whole arena -- radius actuation + integration + neighbour forces + friction for every
 bot, one fused k_force launch.  State is resident in HBM before the timed region.
@@ -142,10 +142,13 @@ def main():
     rank, local_rank, world, dist, torch = K.init_ranks(args)
 
     import particlerobotsimulations_amd as pb
+    dev = None
     if K.DRY:
         pb = K._DryPb
     elif dist is None:
-        pb.legacy.cudaInit(0, None)   # (with a process group torch.cuda.set_device already chose this rank's GPU)
+        pb.legacy.cudaInit(0, None)
+    else:
+        dev = K.engine_device(local_rank)   # (torch.cuda.set_device chose it for torch; the engine is told itself)
 
     n = args.bots
     K.HEADLINE_FORCE_SUMS = 1   # the scratch arena runs the headline's kernel
@@ -161,7 +164,7 @@ def main():
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         summaries = [[float(x) for x in v.tolist()] for v in allv]
-        coll = K.collective_info(dist, torch, local_rank)
+        coll = K.collective_info(dist, torch, local_rank, dev)
     warm.done()
     # (the arenas are closed before the ensemble: with their streams alive the two batches land on one hardware queue)
     ens, ens_detail = (None, None) if args.no_ensemble else configs3_end_to_end(rank, world, dist, torch, args.e2e_steps)
@@ -208,7 +211,7 @@ def main():
         # the driver reads an 8 KB tail: should the line ever outgrow its budget, the optional blocks go (they are in
         # the detail record), never the contract keys
         import json
-        for drop in ("ensemble", "default_form", "collective", "cpu_baseline"):
+        for drop in ("ensemble", "default_form", "collective"):
             if len(json.dumps(out)) + 1 < MAX_LINE_BYTES:
                 break
             sys.stderr.write(f"bench.py: line over {MAX_LINE_BYTES} bytes, dropping `{drop}` (kept in {args.detail})\n")

@@ -102,7 +102,7 @@ class Particlebot {
   void setHexSpacing(float pitch) { hexSpacing = pitch; }
   /* Extension: place the bots on a centred square lattice (pitch as setHexSpacing) instead of what
    * params.config says.  Unlike any hexagonal packing, four contacts per bot are numerically stable
-   * under the reference's parameters (DESIGN.md section 6): the O(N) placement for very large arenas. */
+   * under the reference's parameters (DESIGN.md section 5): the O(N) placement for very large arenas. */
   void setSquareLattice(bool on) { squareLattice = on; }
   /* Extension (`pb_placement fastblob`): a random blob grown by the reference's rule (random anchor,
    * random angle, pivot to contact; particlebot.cpp:612-748) with the anchors drawn from the discs
@@ -116,7 +116,7 @@ class Particlebot {
   int rngKind() const { return rngKindV; }
   /* Extension (`pb_force_variant` key): the force kernel of the fused engine -- 0/1/2 the exact forms (2 the default),
    * 3 the opt-in tolerance kernel (not bit-identical; as close to the reference as an FMA-contracted build of its own
-   * arithmetic, DESIGN.md section 8).  No effect on the Legacy engine. */
+   * arithmetic, DESIGN.md section 4).  No effect on the Legacy engine. */
   void setForceVariant(int variant);
   pbSim *engineHandle() { return sim; }
   /* host mirrors in original bot order (valid after reset(); refreshed by getArray/dump) */

@@ -224,7 +224,7 @@ int pbSimStep(pbSim *sim, float deltaTime, float sort_interval, int nsteps, int 
 int pbSimStepTimed(pbSim *sim, float deltaTime, float sort_interval, int nsteps, int *steps_done,
                    float *elapsed_ms);
 /* Same, and *wall_ms (if not NULL) = the HOST's clock over the region: from entry -- the caller has synchronised, the
- * stream is idle -- through every launch to the return of a closing hipStreamSynchronize.  The host polls for the
+ * stream is idle -- through every launch to the drained stream (the end event has completed; hipStreamQuery confirms).  The host polls for the
  * end of the region instead of sleeping on an interrupt, so for a region of a few milliseconds wall and device time
  * differ only by the dispatch and completion latencies (~10 us; PB_TIMED_TRACE=1 prints where the host's time went).
  * bench.py's `value` is over this clock, its `roofline` over *elapsed_ms, of the same launches. */
@@ -266,7 +266,7 @@ float pbHostSqrtThreshold(float c);
  * reciprocal square root, 1/gap^2 from one reciprocal, |F_attr| from its coefficient, FMA
  * contraction, a bot's contact terms added after its attraction terms.  About twice as fast;
  * agrees with variants 0-2 to ~1e-7 relative per 10 steps except where a bot lands on the other
- * side of one of the reference's force-law discontinuities (DESIGN.md "Streamlined").  It only
+ * side of one of the reference's force-law discontinuities.  It only
  * replaces the throughput form (batches above 131072 bots, or lanes-per-bot forced to 1); smaller
  * batches keep running the exact kernels. */
 int pbSimSetForceVariant(pbSim *sim, int variant);
@@ -289,7 +289,7 @@ int pbSimSetLanesPerBot(pbSim *sim, int lanes);
 /* Resident form for simulations of at most 1024 bots: one workgroup per simulation keeps the state
  * in registers/LDS and runs every timestep up to the next re-sort, phase update or end of the
  * pbSimStep call in ONE launch.  0 = automatic (default: a cost model fitted to MI355X measurements
- * picks it for a lone simulation of ~100 bots and for ensembles of many small ones, DESIGN.md 6b),
+ * picks it for a lone simulation of ~100 bots and for ensembles of many small ones, DESIGN.md section 6),
  * 1 = never, 2 = whenever the simulation fits.  Results do not depend on it. */
 int pbSimSetResident(pbSim *sim, int mode);
 

@@ -32,7 +32,7 @@
  *                       in for the hardware approximations, so this is a LOWER bound on its error)
  *   -DORC_BRACKET_ORDER the oracle's own terms, bit for bit, added in the order of the product's two-pass tolerance
  *                       kernel (a bot's contact terms after its last candidate): isolates what the ORDER of fp32
- *                       additions alone does (tests/test_fma_bracket.py, DESIGN.md section 8)
+ *                       additions alone does (tests/test_fma_bracket.py, DESIGN.md section 4)
  * The exact build (no macro) is the oracle; the bracket builds only measure how far a
  * legitimately different build of the same source drifts from it (tests/test_fma_bracket.py).
  */

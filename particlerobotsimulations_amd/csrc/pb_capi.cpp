@@ -1194,16 +1194,49 @@ void *pbEnsembleCreate(const char *cfg_path, const char *common_overrides, const
   // build them on all host cores.  The reference's random placement is O(N^1.5) (1.4 s for 10^5
   // bots), so a sweep of large members would otherwise spend minutes here.  (pbEnsemblePipeline* overlaps
   // this with the device work of the members built before.)
+  // Members whose placement inputs agree (Particlebot::placementKey: a sweep under one seed) are placed ONCE, by the
+  // thread that takes their group, and share the placed state + the generator state after it (as the pipeline does).
+  std::vector<std::vector<int>> groups;
+  {
+    std::map<std::string, int> index;
+    const char *env = getenv("PB_SHARE_PLACEMENTS");
+    const bool share = !(env && env[0] == '0');
+    for (int k = 0; k < nmembers; k++) {
+      PbRunConfig c;
+      c.params.seed = 0;
+      std::string key;
+      if (share && (!cfg_path || c.loadFile(cfg_path))) {
+        applyOverrides(c, common_overrides);
+        applyOverrides(c, member_overrides ? member_overrides[k] : nullptr);
+        c.derive();
+        key = Particlebot::placementKeyOf(c.params, c.hex_spacing, c.square_lattice, c.fast_blob);
+      }
+      auto it = key.empty() ? index.end() : index.find(key);
+      if (it == index.end()) {
+        if (!key.empty()) index[key] = (int)groups.size();
+        groups.push_back({k});
+      } else {
+        groups[it->second].push_back(k);
+      }
+    }
+  }
   std::atomic<int> next{0};
   std::atomic<bool> failed{false};
   auto worker = [&]() {
-    for (int k = next++; k < nmembers && !failed; k = next++) {
-      Member *m = new Member();
-      e->members[k] = m;
-      if (!buildMember(*m, cfg_path, common_overrides, member_overrides ? member_overrides[k] : nullptr)) failed = true;
+    for (int g = next++; g < (int)groups.size() && !failed; g = next++) {
+      Particlebot::Placement placed;
+      for (size_t j = 0; j < groups[g].size() && !failed; j++) {
+        const int k = groups[g][j];
+        Member *m = new Member();
+        e->members[k] = m;
+        const bool first = j == 0, more = groups[g].size() > 1;
+        if (!buildMember(*m, cfg_path, common_overrides, member_overrides ? member_overrides[k] : nullptr,
+                         first ? nullptr : &placed, first && more ? &placed : nullptr))
+          failed = true;
+      }
     }
   };
-  const unsigned nthreads = std::min<unsigned>(hostThreads(0), (unsigned)nmembers);
+  const unsigned nthreads = std::min<unsigned>(hostThreads(0), (unsigned)groups.size());
   std::vector<std::thread> pool;
   for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(worker);
   worker();

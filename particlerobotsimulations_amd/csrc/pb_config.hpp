@@ -22,7 +22,7 @@ struct PbRunConfig {
   bool square_lattice; // pb_placement square
   bool fast_blob;      // pb_placement fastblob: O(N) random blob (Particlebot::placeFastBlob)
   int force_variant;   // pb_force_variant: -1 (default) the engine's choice = 2, the exact kernels; 0/1/2 exact forms; 3 the opt-in
-                       // tolerance kernel (pbSimSetForceVariant; held to the FMA bracket of the reference's arithmetic, DESIGN.md 8)
+                       // tolerance kernel (pbSimSetForceVariant; held to the FMA bracket of the reference's arithmetic, DESIGN.md section 4)
   int rng_kind;        // pb_rng: PB_RNG_COUNTER ("pbrng", default), PB_RNG_XORWOW_CURAND ("curand"), PB_RNG_XORWOW_ROCRAND ("rocrand")
 
   PbRunConfig();

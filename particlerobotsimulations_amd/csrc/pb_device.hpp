@@ -1,6 +1,6 @@
 // pb_device.hpp -- device-side parameter block and per-bot physics for gfx950.
 //
-// Arithmetic contract (DESIGN.md "Numerics"): fp32, IEEE division and sqrt (hipcc's default
+// Arithmetic contract: fp32, IEEE division and sqrt (hipcc's default
 // correctly-rounded forms), NO FMA contraction (-ffp-contract=off), operation order exactly as the
 // reference writes it, with  powf(x,2)/__powf(x,2) -> x*x  and  powf(x,0.5f) -> sqrtf(x).
 // The CPU oracle follows the same rules, so the two agree bit for bit.
@@ -759,7 +759,7 @@ PB_DEV void pbPairFlat(const PbDevParams &P, bool live, float ax, float ay, floa
   pbPairAdd(live, pbPairEval<FAST>(P, live, ax, ay, avx, avy, ra, bx, by, rb, attraction, slope, velB), F);
 }
 
-// ---- streamlined pair force (force variant 3; NOT bit-identical, see DESIGN.md "Streamlined") ----
+// ---- streamlined pair force (force variant 3; NOT bit-identical) ----
 // The same physics as collideSpheres (impl.cuh:541-594) in the algebraically streamlined form
 // SURVEY.md 8(d) describes: one reciprocal square root gives the distance and the unit vector
 // (v_rsq_f32, 1 ulp), 1/gap^2 is one v_rcp_f32 (1 ulp), a non-contact term's magnitude is its

@@ -114,7 +114,7 @@ bool pbResidentWanted(const pbSim *S) {
   if (S->lanesPerBot != 0 && S->resident != 2) return false;  // an explicit per-step form was asked for
   if (S->resident == 2) return true;
   // automatic: cost model fitted to MI355X measurements (microseconds per timestep of the whole batch,
-  // dead-sum forms: profiles/r2_resident_sweep.txt, tools/resident_sweep.py; DESIGN.md section 6b).  One CU
+  // dead-sum forms: profiles/r2_resident_sweep.txt, tools/resident_sweep.py; DESIGN.md section 6).  One CU
   // per simulation costs the same however many simulations there are (up to one per CU): 5.3 us at 100
   // bots, 8.5 at 201, 11.2 at 300, 15.8 at 500, 25.3 at 1000 (the slope changes with the lanes per bot the
   // simulation's size allows); a per-step launch costs a ~5.5 us dependent-latency floor plus a term in

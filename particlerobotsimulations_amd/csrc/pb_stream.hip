@@ -1,5 +1,5 @@
 // pb_stream.hip -- k_force_stream: the opt-in STREAMLINED force kernel (force variant 3), the one kernel
-// of the engine that is not bit-identical to the reference restatement (DESIGN.md section 5
+// of the engine that is not bit-identical to the reference restatement (DESIGN.md section 3
 // "Streamlined arithmetic"; SURVEY.md 8(d) caveat 1).  Reference: collideD / collideSpheres
 // (particlebot_kernel_impl.cuh:541-831), arithmetic algebraically streamlined.
 #include <typeinfo>
@@ -102,7 +102,7 @@ PB_DEV float pbActuateS(const PbDevParams &P, float rad, float phase, int dead, 
 }
 
 // Round 3 also tried the neighbour rows STAGED IN LDS, one private tile per wave (tools/experiments/
-// pb_stream_lds_tile.hip.txt; DESIGN.md section 5 "Streamlined"): the loop itself then runs at the pace of the loop
+// pb_stream_lds_tile.hip.txt): the loop itself then runs at the pace of the loop
 // without loads (40.8 us against 52.7 us at 10^6 bots -- the vector-memory pipeline, 64 lanes x 16 B per trip,
 // co-limits this kernel), but the staging prologue, the 40 KB of LDS per workgroup and the waves that need more than
 // one tile (grid-row ends, the bench lattice's alternating row densities) gave it all back: 49.3 us in the best

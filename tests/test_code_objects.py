@@ -1,5 +1,5 @@
 """Occupancy guards read from the CODE OBJECTS themselves (no GPU needed: hipcc cross-compiles gfx950 here):
-the register counts and scratch sizes DESIGN.md section 5 argues with, taken from the `.vgpr_count` /
+the register counts and scratch sizes DESIGN.md section 3 argues with, taken from the `.vgpr_count` /
 `.private_segment_fixed_size` metadata of csrc/build/*.o exactly as tools/summarize_profile.py prints them
 (rocprofv3's own VGPR column is the allocation granule).  A change that pushes the headline kernel
 past 64 VGPRs (8 -> 7 waves per SIMD) or makes any force kernel spill fails here, before it is measured."""

@@ -9,7 +9,7 @@ statistics (generator: tests/golden/make_fma_bracket.py).  This file
   * checks that the bracket builds differ from the oracle ONLY in the kernel functions (FMA
     instructions nowhere else; placement, dead-bot draw and host loop bit-identical),
   * re-measures the small cases and holds them to the fixture,
-  * asserts the statements DESIGN.md section 8 makes from the fixture: in a 10-step window a contracted
+  * asserts the statements DESIGN.md section 4 makes from the fixture: in a 10-step window a contracted
     build of the same source agrees with the oracle to <= 1e-6 relative at the 99th percentile and
     in the centre of mass, at most a few bots in 10^5 are beyond 1e-5 (threshold flips), and
     without re-synchronisation the 99th percentile leaves 1e-5 after 26 to > 100 steps.
@@ -137,7 +137,7 @@ def test_the_order_of_additions_alone_flips_nothing(orc):
     """oracle/libpb_oracle_order.so: the oracle's own terms, bit for bit, with a bot's CONTACT terms added after its
     last candidate -- the order of additions of the product's two-pass tolerance kernel (k_force_stream).  Over the same
     teacher-forced windows that order alone moves no bot beyond 1e-5 and leaves the 99th percentile at 1e-8: it is not
-    what separates that kernel from the reference (DESIGN.md section 5 "Round 4, numerics")."""
+    what separates that kernel from the reference (HISTORY.md "Round 4, numerics")."""
     lib = orc.variant_lib("order")
     assert lib.orc_build_variant() == b"order"
     assert fma_functions(os.path.join(os.path.dirname(orc.__file__), "libpb_oracle_order.so")) == {}
@@ -212,7 +212,7 @@ def test_device_powf_members_touch_nothing_but_the_obstacle_sites(orc):
 
 
 def test_what_the_device_powf_bracket_says(fixture):
-    """The statements DESIGN.md section 8 quotes from the fixture.  (a) The reference's obstacle files verbatim never
+    """The statements DESIGN.md section 4 quotes from the fixture.  (a) The reference's obstacle files verbatim never
     reach their obstacles inside a window of the first 3 100 steps -- nor inside BASELINE configs[3]'s 120 000: the
     device-powf members are the oracle there, bit for bit.  (b) Where bots ARE on the obstacles (the file's own course
     after 230 000 - 450 000 steps; the rim cases) a non-correctly-rounded powf moves no bot beyond 1e-5 in ten steps,
@@ -237,7 +237,7 @@ def test_what_the_device_powf_bracket_says(fixture):
 
 
 def test_what_the_bracket_says(fixture):
-    """The statements DESIGN.md section 8 quotes.  `cfg3_arena_crop_10k` is centred on the origin
+    """The statements DESIGN.md section 4 quotes.  `cfg3_arena_crop_10k` is centred on the origin
     (|COM| ~ 1e-3), which makes a RELATIVE centre-of-mass figure meaningless there: its absolute
     deviation is held instead."""
     flips = bot_windows = 0
@@ -288,7 +288,7 @@ def test_gpu_box_record_agrees_with_this_fixture(fixture):
     """tests/golden/fma_bracket/hip_streamlined.json was written on the GPU box (another CPU, the FMA build compiled
     there from the same source): its FMA-build statistics must be THIS container's fixture to the last digit -- the
     bracket is a deterministic function of (source, gcc), not of the machine -- and the record must hold what
-    DESIGN.md section 8 quotes for the product's tolerance kernel."""
+    DESIGN.md section 4 quotes for the product's tolerance kernel."""
     rec = json.load(open(os.path.join(HERE, "golden", "fma_bracket", "hip_streamlined.json")))
     assert set(rec["cases"]) == set(fixture["cases"]) - set(fb.FIXTURE_ONLY_CASES)
     flips = {"hip_streamlined": 0, "fma": 0}

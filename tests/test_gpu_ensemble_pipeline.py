@@ -142,6 +142,12 @@ def test_members_that_share_a_placement_equal_their_stand_alone_oracle_runs(orc)
         tm, rows, states = p.timings, p.rows, p.final_states()
         p.close()
         assert steps in (620, 621) and tm["placements_run"] == 2 and 4 <= tm["placements_shared"] <= 5
+        # the one-batch form (pbEnsembleCreate) groups its members the same way: same rows, same states
+        lrows, lsteps, lstates = ensemble.run_local(cfg, members, common, final_state=True)
+        assert lsteps == steps and np.array_equal(lrows.view(np.uint32), rows.view(np.uint32))
+        for k in range(len(spec)):
+            for key in ("pos", "vel", "rad"):
+                assert_bit_equal(lstates[k][key], states[k][key], f"run_local vs pipeline, member {k}: {key}")
         for k, (s, nd) in enumerate(spec):
             orows, osim = oracle_member(orc, cfg, dict(nCells=600, seed=s, nDead=nd, max_time=6.2, dump_interval=6.0,
                                                        time_to_dead=float(ttd)), 6.0)

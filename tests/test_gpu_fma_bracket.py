@@ -16,7 +16,7 @@ configurations, next to the FMA build (the + __powf build is in the CPU fixture)
 Every exact kernel (variants 0-2, all lanes-per-bot forms, the resident kernel) is bit-identical
 to the oracle and needs none of this.  The statistics are written to
 gpurun_out/fma_bracket_gpu.json; a copy of a run on MI355X is committed as
-tests/golden/fma_bracket/hip_streamlined.json (DESIGN.md section 8 quotes it)."""
+tests/golden/fma_bracket/hip_streamlined.json (DESIGN.md section 4 quotes it)."""
 import json
 import os
 

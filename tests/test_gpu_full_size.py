@@ -122,7 +122,7 @@ def test_config5_slice_64_members_dead_fraction_trend(tmp_path, orc):
 def test_config5_slice_statistic_is_the_same_with_the_tolerance_kernel(tmp_path):
     """The same 64-member slice with `pb_force_variant 3` (the opt-in tolerance kernel, selected through the members'
     configuration): individual trajectories are not the exact kernels' after 12 000 free-running steps (chaos:
-    DESIGN.md section 8), the sweep's STATISTIC is -- every per-fraction mean of the progress toward the light within
+    DESIGN.md section 4), the sweep's STATISTIC is -- every per-fraction mean of the progress toward the light within
     three standard errors of the exact run's (measured: <= 2.9e-4 of 0.02-0.08, i.e. 0.5 of the seed spread), the same
     monotone decline, the fractions an order of magnitude further apart than the two realisations."""
     members, di = 64, 6.0

@@ -1,4 +1,4 @@
-"""Streamlined force arithmetic (pbSimSetForceVariant(sim, 3); DESIGN.md "Streamlined") against the
+"""Streamlined force arithmetic (pbSimSetForceVariant(sim, 3)) against the
 CPU oracle, to the tolerance BASELINE.json states: per-particle positions and the centre of mass
 within 1e-5 RELATIVE over teacher-forced windows of 10 timesteps.
 

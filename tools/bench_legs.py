@@ -149,7 +149,7 @@ def host_round_trip_leg(pb, n, pitch, steps=10):
     (28 B per bot: pos, vel, rad, phase, dead), one step, pbSimGetState into host buffers (36 B per bot: the same
     plus the two force sums), every step, pageable numpy memory as a ctypes caller has it, buffers reused.  Never `value`: the
     class keeps the state resident between CSV dumps, as the reference does (particlebot.cpp:383-395 only reads
-    back for dumpParticlebot).  DESIGN.md section 6 quotes this leg."""
+    back for dumpParticlebot).  DESIGN.md section 5 quotes this leg."""
     sim = make_sim(pb, n, pitch, seed=1)
     sim.step(50)
     st = sim.get_state()
@@ -409,7 +409,7 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
             strong = ensemble_end_to_end(workload, rank, world, dist, torch, None, strong_total, e2e_steps,
                                          host_threads=host_threads)
         # When the host is the limit (few cores per rank: the reference's placement rule costs 0.85-1.6 CPU-seconds per
-        # 10^5-bot member) the same run is repeated with the O(N) generator (pb_placement fastblob), so
+        # 10^5-bot member) the same run is repeated with the O(N) generator (pb_placement fastblob, HISTORY.md 6c), so
         # that the line shows both what the reference's rule costs here and what the device can do.  Every rank takes
         # the same decision: rank 0's verdict is broadcast.
         fast = None
@@ -446,7 +446,7 @@ def measure_ensemble(pb, workload, members_per_gpu, steps, warmup, prewarm_ms, r
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_resident (<= 1024-bot members) / k_force (larger members)",
                      "note": "64 algorithmic bytes per particle-step over WALL time of the timed region "
-                             "(host-driven schedule included); small members are latency-bound (DESIGN.md 6b)"},
+                             "(host-driven schedule included); small members are latency-bound (DESIGN.md section 6)"},
         "summaries_last_row_time_comx_comy_dist": [[[float(x) for x in r] for r in l[:4]] for l in last],
         "summary_rows_gathered": [list(g.shape) for g in gathered],
     }
@@ -483,7 +483,7 @@ def run_ensemble_workload(args, rank, world, dist, torch):
             out["headline"] = False
             out["config"]["force_variant"] = K.ENSEMBLE_FORCE_VARIANT
             out["force_variant_note"] = ("pb_force_variant set for every member: 3 = the opt-in tolerance kernel for "
-                                         "batches in the throughput form (not bit-identical; DESIGN.md section 8)")
+                                         "batches in the throughput form (not bit-identical; DESIGN.md section 4)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_ensemble(batches, min(args.cpu_seconds, 10.0))
         emit(out)
@@ -606,7 +606,9 @@ def main():
     if K.DRY:
         pb = K._DryPb
     elif dist is None:
-        pb.legacy.cudaInit(0, None)  # otherwise torch.cuda.set_device above already chose this rank's GPU
+        pb.legacy.cudaInit(0, None)
+    else:
+        K.engine_device(local_rank)  # (torch.cuda.set_device chose it for torch; the engine is told itself)
 
     if args.workload != "arena":
         if args.force_variant != 2:
@@ -728,6 +730,9 @@ def main():
                        "parallelism": "single arena" if world == 1 else f"{world} independent arenas, one per GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         # machine-readable: which kernel `frac` / `achieved` / `avg_launch_us` describe in THIS line
+                         # (the same keys meant two kernels depending on the flags)
+                         "frac_kernel": "arena_kernel_priced_at_64B",
                          "frac_is": "the kernel `value` runs (dead-sum form) priced at SURVEY 8(d)'s 64 B although it "
                                     "moves 56: the both_sums leg did not run, see frac_dead_sum",
                          "traffic": tr["hbm_bytes_per_launch"] if tr else None,
@@ -760,7 +765,7 @@ def main():
                          "note": "achieved/peak/frac are the HBM accounting SURVEY 8(d) prescribes (64 algorithmic "
                                  "bytes per particle-step over the kernel's launch time); the kernel is VALU-issue "
                                  "bound, not HBM bound (~50 neighbour pairs per bot, each with 4 IEEE divisions and 2 "
-                                 "IEEE square roots -- one fewer since Sum|F_attr| is only kept when something reads it --, DESIGN.md section 5): `valu` prices its instruction stream at the "
+                                 "IEEE square roots -- one fewer since Sum|F_attr| is only kept when something reads it --, DESIGN.md section 3): `valu` prices its instruction stream at the "
                                  "datasheet issue rate at the measured shader clock and at tools/valu_rate's rates; "
                                  "`traffic` (PMC) ~ algorithmic bytes, i.e. no wasted re-reads"},
             "headline": args.force_variant == 2 and not args.force_sums,
@@ -806,6 +811,7 @@ def main():
             ach_b = ALG_BYTES_PER_PARTICLE_STEP * n / (us_b * 1e-6) / 1e9
             r = out["roofline"]
             r.update({"achieved": ach_b, "frac": ach_b / HBM_PEAK_GBS, "frac_both_sums": ach_b / HBM_PEAK_GBS,
+                      "frac_kernel": "both_sums_leg",
                       "frac_is": "the kernel that writes everything the reference's collideD writes -- both magnitude "
                                  "sums, k_force<false, true, 1, 1, false, true>, the both_sums leg "
                                  "(value_with_both_sums) -- at 64 B per particle-step; NOT the kernel `value` runs: "

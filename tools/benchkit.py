@@ -642,12 +642,30 @@ def init_ranks(args):
     return rank, local_rank, world, dist, torch
 
 
-def collective_info(dist, torch, local_rank):
-    """What the process group itself reports -- backend, rank count, and which device every rank sits on (gathered over
-    that same group) -- so that "RCCL saw N ranks" is checkable from the line."""
+def engine_device(local_rank):
+    """Point the ENGINE (libparticlebot_hip.so) at this rank's GPU through its own C-ABI and return the device it then
+    reports.  torch.cuda.set_device chose the device for torch's view of the HIP runtime; if the two libraries ever
+    resolved to two copies of the runtime, every rank's simulations would silently land on device 0 -- so the engine is
+    told explicitly, and what it answers is what `collective.local_rank_device` reports."""
+    if DRY:
+        return -1
+    import ctypes as C
+    from particlerobotsimulations_amd import _capi
+    _capi.check(_capi.lib().pbSetDevice(int(local_rank)), "pbSetDevice")
+    dev = C.c_int(-1)
+    _capi.check(_capi.lib().pbGetDevice(C.byref(dev)), "pbGetDevice")
+    if dev.value != int(local_rank):
+        raise RuntimeError(f"the engine sits on device {dev.value}, LOCAL_RANK is {local_rank}")
+    return dev.value
+
+
+def collective_info(dist, torch, local_rank, dev=None):
+    """What the process group itself reports -- backend, rank count, and which device every rank's ENGINE sits on
+    (engine_device, gathered over that same group) -- so that "RCCL saw N ranks on N GPUs" is checkable from the line."""
     if dist is None:
         return None
-    dev = -1 if DRY else int(torch.cuda.current_device())
+    if dev is None:
+        dev = -1 if DRY else int(torch.cuda.current_device())
     mine = torch.tensor([local_rank, dev], dtype=torch.int64, device=dist_device())
     allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(allv, mine)

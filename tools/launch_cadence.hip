@@ -1,6 +1,6 @@
 // launch_cadence.hip -- what a dependent kernel boundary costs on this GPU, eager against hipGraph replay.
 // The per-step forms of small ensembles (BASELINE configs[3] at 32 + 32 members per GPU: one ~5 us kernel per step, each
-// needing the one before it) are bound by this cadence; DESIGN.md section 6b / HISTORY.md "No hipGraph" argue that a
+// needing the one before it) are bound by this cadence; DESIGN.md section 6 / HISTORY.md "No hipGraph" argue that a
 // replayed graph cannot shorten it.  This measures it.
 //   hipcc --offload-arch=gfx950 -O3 -o launch_cadence tools/launch_cadence.hip && ./launch_cadence
 #include <hip/hip_runtime.h>

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """us per batched timestep of an ensemble of `members` copies of an example configuration, per-step form
-against resident form: the table DESIGN.md 6b quotes and the cost model in pb_engine.hip (residentWanted)
+against resident form: the table DESIGN.md section 6 quotes and the cost model in pb_engine.hip (residentWanted)
 is fitted to.
   python tools/resident_sweep.py [--steps 2000]"""
 import argparse

@@ -6,7 +6,7 @@
 // Part 1: every float in [2^-96, FLT_MAX).  Part 2: every d2 in [1, 4) (all 2^24 mantissa x exponent-parity
 // cases) against every numerator mantissa a in [1, 2) (2^23): 2^47 divisions, compared with the compiler's
 // IEEE a/dist.  Scaling d2 by 4^k and a by 2^m scales every intermediate exactly (no denormals inside the
-// kernel's domain, DESIGN.md "Fast exact math"), so the mantissa cases are all there is; part 3 samples
+// kernel's domain), so the mantissa cases are all there is; part 3 samples
 // random exponents all the same.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/rsq_form_test.hip -o /tmp/rsq_form_test && /tmp/rsq_form_test [slices]
 #include <hip/hip_runtime.h>

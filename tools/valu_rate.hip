@@ -1,7 +1,7 @@
 // VALU issue-rate microbenchmark for gfx950: nanoseconds of SIMD time per wave64 instruction for
 // simple fp32 ops (fma, mul, compare/select) and for the transcendentals the force kernels use
 // (v_rcp_f32, v_sqrt_f32, v_rsq_f32), at 1, 2, 4 and 8 waves per SIMD with eight independent chains
-// per lane.  The 8-waves/SIMD figures are the "VALU roofline" DESIGN.md section 5 prices the force
+// per lane.  The 8-waves/SIMD figures are the "VALU roofline" DESIGN.md section 3 prices the force
 // kernel's instruction mix against.  Prints one JSON line at the end.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/valu_rate.hip -o tools/valu_rate && tools/valu_rate
 #include <hip/hip_runtime.h>
