@@ -103,8 +103,13 @@ int pbEnsemblePipelineSetCsvDir(void *pipeline, const char *dir, const int *ids)
  * never more than that many bots whatever the size of the pool. */
 int pbEnsemblePipelineAutoSubBatch(unsigned bots_per_member, int producers);
 unsigned pbEnsemblePipelineNumBots(void *pipeline);
-/* Placements computed / members that took a copy of another member's placement, so far (pbEnsembleTimings carries the
- * same two after a Run; this getter also serves the device-less DryRun). */
+/* ONE PLACEMENT PER DISTINCT BLOB.  Members of a pipeline (and of pbEnsembleCreate) whose placement inputs agree --
+ * Particlebot::placementKey(): seed, nCells, radii, payload mode, placement kind, lattice pitch, grid; NOT nDead >= 0,
+ * light position or anything else the placement does not read (reference particlebot.cpp:612-748) -- are placed once;
+ * the others take a copy of the placed state and of the private libc-rand state after the placement, so their dead
+ * draw continues the same stream (particlebot.cpp:178-194): every member is bit-identical to its stand-alone run.
+ * PB_SHARE_PLACEMENTS=0 in the environment switches it off.  The getter: placements computed / members that took a
+ * copy, so far (pbEnsembleTimings carries the same two after a Run; this also serves the device-less DryRun). */
 void pbEnsemblePipelinePlacementCounts(void *pipeline, int *run, int *shared);
 int pbEnsemblePipelineGetState(void *pipeline, int member, float *pos, float *vel, float *rad);
 /* The consumer side without a device (CPU tests): takes the sub-batches in order as Run does, records a checksum

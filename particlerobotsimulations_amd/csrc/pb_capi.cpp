@@ -982,7 +982,6 @@ struct Pipeline {
   struct SharedPlacement {
     int state = 0;      // 0 nobody has started it, 1 being placed, 2 ready, -1 failed
     int usesLeft = 0;   // members that still have to take it (freed at 0)
-    int firstMember = 0;
     Particlebot::Placement placed;
   };
   std::vector<int> keyOf;
@@ -1012,7 +1011,6 @@ struct Pipeline {
       if (g.second.size() < 2) continue;
       SharedPlacement sp;
       sp.usesLeft = (int)g.second.size();
-      sp.firstMember = g.second.front();
       for (int k : g.second) keyOf[k] = (int)shared.size();
       shared.push_back(std::move(sp));
     }

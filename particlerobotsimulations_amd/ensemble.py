@@ -350,6 +350,10 @@ def main():
         torch.cuda.set_device(local_rank)
         device = f"cuda:{local_rank}"
         dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        # the engine is pointed at this rank's GPU through its own C-ABI too (torch.cuda.set_device did it for torch's
+        # view of the runtime; the batches must not depend on the two sharing one)
+        from . import _capi
+        _capi.check(_capi.lib().pbSetDevice(local_rank), "pbSetDevice")
     sweep = (args.sweep[0], args.sweep[1:]) if args.sweep else None
     ids = shard(args.members, rank, world)
     t0 = time.perf_counter()

@@ -107,11 +107,7 @@ def test_eight_rank_headline_line_is_small_and_names_eight_devices(tmp_path):
     assert len(long["summaries_time_comx_comy"]) == 8
 
 
-def test_cxx_runner_id_exchange_world_size_8_with_a_stray():
-    """bin/particlebot_ensemble's rendezvous with SEVEN clients under one deadline, started before rank 0 serves, and
-    one stray connection (right magic, wrong launch token) in between."""
-    if not os.path.exists(EXE):
-        pytest.skip("runner not built")
+def _id_exchange_eight_ranks_once():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -123,12 +119,27 @@ def test_cxx_runner_id_exchange_world_size_8_with_a_stray():
     time.sleep(0.3)
     procs.append(subprocess.Popen([EXE, "--rendezvous-test"], env=env(0), stdout=subprocess.PIPE, text=True))
     time.sleep(0.2)
-    c = socket.create_connection(("127.0.0.1", port), timeout=5)
-    c.sendall(b"PBID" + (2).to_bytes(4, "little") + bytes(8))   # claims to be rank 2 of another launch
-    time.sleep(0.2)
-    c.close()
+    try:
+        c = socket.create_connection(("127.0.0.1", port), timeout=5)
+        c.sendall(b"PBID" + (2).to_bytes(4, "little") + bytes(8))   # claims to be rank 2 of another launch
+        time.sleep(0.2)
+        c.close()
+    except OSError:
+        pass   # (rank 0 not listening yet on a loaded machine: the exchange itself is still checked below)
     procs += [subprocess.Popen([EXE, "--rendezvous-test"], env=env(r), stdout=subprocess.PIPE, text=True)
               for r in (2, 4, 6)]
     outs = [p.communicate(timeout=90)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    return all(p.returncode == 0 for p in procs), outs
+
+
+def test_cxx_runner_id_exchange_world_size_8_with_a_stray():
+    """bin/particlebot_ensemble's rendezvous with SEVEN clients under one deadline, started before rank 0 serves, and
+    one stray connection (right magic, wrong launch token) in between.  (The port is found by bind-and-close, which
+    another process of a busy CI box may win before rank 0 binds it: one retry on a fresh port.)"""
+    if not os.path.exists(EXE):
+        pytest.skip("runner not built")
+    ok, outs = _id_exchange_eight_ranks_once()
+    if not ok:
+        ok, outs = _id_exchange_eight_ranks_once()
+    assert ok, outs
     assert sorted(o.strip() for o in outs) == [f"rendezvous-test rank {r} of 8: ok" for r in range(8)]

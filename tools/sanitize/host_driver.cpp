@@ -26,6 +26,7 @@ void *pbEnsemblePipelineCreate(const char *cfg, const char *common, const char *
 int pbEnsemblePipelineDryRun(void *p, int dwell_ms, unsigned long long *checksums, int *max_ahead);
 int pbEnsemblePipelineHostThreads(void *p);
 void pbEnsemblePipelineDestroy(void *p);
+void pbEnsemblePipelinePlacementCounts(void *p, int *run, int *shared);
 }
 int main(int argc, char **argv) {
   const char *root = argv[1];
@@ -115,6 +116,28 @@ int main(int argc, char **argv) {
       printf("pipeline sub %d: %d producers, look-ahead %d\n", sub, pbEnsemblePipelineHostThreads(p), ahead);
       pbEnsemblePipelineDestroy(p);
     }
+    // shared placements (round 6): 3 seeds x 4 dead fractions -- three placements, nine copies -- with more producers
+    // than groups (look-ahead placement, waits on the group's condition variable) and with one; a pipeline destroyed
+    // before anything was consumed (producers stopped in mid-wait)
+    const char *sweep[12] = {"seed\n7\nnDead\n0", "seed\n7\nnDead\n3", "seed\n7\nnDead\n9", "seed\n7\nnDead\n12",
+                             "seed\n8\nnDead\n0", "seed\n8\nnDead\n3", "seed\n8\nnDead\n9", "seed\n8\nnDead\n12",
+                             "seed\n9\nnDead\n0", "seed\n9\nnDead\n3", "seed\n9\nnDead\n9", "seed\n9\nnDead\n12"};
+    snprintf(path, sizeof path, "%s/examples/example_dead_cells.cfg", root);
+    unsigned long long first[12] = {0};
+    for (int threads : {6, 1, 3}) {
+      void *p = pbEnsemblePipelineCreate(path, "nCells\n300\nmax_time\n1", sweep, 12, 5, threads, 0);
+      if (!p) { printf("sweep pipeline create failed\n"); return 1; }
+      unsigned long long sums[12];
+      int ahead = 0, run = 0, shared = 0;
+      if (pbEnsemblePipelineDryRun(p, 0, sums, &ahead) != 0) { printf("sweep dry run failed\n"); return 1; }
+      pbEnsemblePipelinePlacementCounts(p, &run, &shared);
+      if (threads == 6) memcpy(first, sums, sizeof sums);
+      printf("sweep with %d producers: %d placements, %d copies, checksums %s\n", threads, run, shared,
+             memcmp(first, sums, sizeof sums) == 0 ? "equal" : "DIFFER");
+      pbEnsemblePipelineDestroy(p);
+    }
+    void *p = pbEnsemblePipelineCreate(path, "nCells\n2000\nmax_time\n1", sweep, 12, 2, 4, 0);
+    pbEnsemblePipelineDestroy(p);   // (nothing consumed: the producers are stopped where they are)
   }
   printf("asan driver done\n");
   return 0;
