@@ -69,7 +69,9 @@ def test_headline_line_through_rccl_with_one_rank(tmp_path):
     lines = [l for l in raw.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines[:3]      # ONE line on stdout: RCCL's version banner goes to stderr
     d = json.loads(lines[0])
-    assert d["collective"] == {"backend": "rccl", "torch_backend": "nccl", "ranks": 1, "local_rank_device": [[0, 0]]}
+    c = d["collective"]
+    assert (c["backend"], c["torch_backend"], c["ranks"], c["local_rank_device"]) == ("rccl", "nccl", 1, [[0, 0]])
+    assert c["distinct_gpus"] == 1 and len(c["pci_bus_ids"]) == 1 and ":" in c["pci_bus_ids"][0]   # e.g. 0000:c1:00.0
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["ensemble"]["rows_gathered"] == [[256, 2, 4], [256, 2, 4]]
     long = json.loads((tmp_path / "d.json").read_text())
     assert len(long["summaries_time_comx_comy"]) == 1

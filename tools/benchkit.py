@@ -630,9 +630,14 @@ def init_ranks(args):
         if DRY:
             dist.init_process_group(backend="gloo", store=store, rank=rank, world_size=world)
         else:
-            torch.cuda.set_device(local_rank)
+            # LOCAL_RANK is the device index unless the launcher already narrowed each rank's view to its own GPU
+            # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank): then every rank sees one device, index 0
+            global DEVICE_INDEX
+            ndev = torch.cuda.device_count()
+            DEVICE_INDEX = local_rank if local_rank < ndev else local_rank % max(ndev, 1)
+            torch.cuda.set_device(DEVICE_INDEX)
             dist.init_process_group(backend="nccl", store=store, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+                                    device_id=torch.device("cuda", DEVICE_INDEX))
         assert dist.get_world_size() == world
         dist.barrier()   # (the communicator and RCCL's kernels are set up here, not inside a measurement's first barrier)
     except Exception as e:
@@ -640,6 +645,9 @@ def init_ranks(args):
         sys.stderr.flush()
         os._exit(2)
     return rank, local_rank, world, dist, torch
+
+
+DEVICE_INDEX = None   # init_ranks: the device index of this rank as the process sees it
 
 
 def engine_device(local_rank):
@@ -651,24 +659,38 @@ def engine_device(local_rank):
         return -1
     import ctypes as C
     from particlerobotsimulations_amd import _capi
-    _capi.check(_capi.lib().pbSetDevice(int(local_rank)), "pbSetDevice")
+    want = int(local_rank) if DEVICE_INDEX is None else int(DEVICE_INDEX)
+    _capi.check(_capi.lib().pbSetDevice(want), "pbSetDevice")
     dev = C.c_int(-1)
     _capi.check(_capi.lib().pbGetDevice(C.byref(dev)), "pbGetDevice")
-    if dev.value != int(local_rank):
-        raise RuntimeError(f"the engine sits on device {dev.value}, LOCAL_RANK is {local_rank}")
+    if dev.value != want:
+        raise RuntimeError(f"the engine sits on device {dev.value}, this rank's device is {want} (LOCAL_RANK {local_rank})")
     return dev.value
 
 
 def collective_info(dist, torch, local_rank, dev=None):
     """What the process group itself reports -- backend, rank count, and which device every rank's ENGINE sits on
-    (engine_device, gathered over that same group) -- so that "RCCL saw N ranks on N GPUs" is checkable from the line."""
+    (engine_device; index and PCI bus id, gathered over that same group) -- so that "RCCL saw N ranks on N distinct
+    GPUs" is checkable from the line, also when a launcher narrowed every rank's view to one device (index 0 everywhere)."""
     if dist is None:
         return None
     if dev is None:
         dev = -1 if DRY else int(torch.cuda.current_device())
-    mine = torch.tensor([local_rank, dev], dtype=torch.int64, device=dist_device())
+    bus = b""
+    if not DRY:
+        import ctypes as C
+        from particlerobotsimulations_amd import _capi
+        buf = C.create_string_buffer(32)
+        if _capi.lib().pbDevicePciBusId(int(dev), buf, len(buf)) == 0:
+            bus = buf.value[:16]
+    mine = torch.tensor([local_rank, dev] + list(bus.ljust(16, b"\0")), dtype=torch.int64, device=dist_device())
     allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(allv, mine)
-    pairs = [[int(x) for x in v.tolist()] for v in allv]
-    return {"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "torch_backend": dist.get_backend(),
-            "ranks": dist.get_world_size(), "local_rank_device": pairs}
+    rows = [[int(x) for x in v.tolist()] for v in allv]
+    buses = [bytes(r[2:]).rstrip(b"\0").decode(errors="replace") for r in rows]
+    out = {"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "torch_backend": dist.get_backend(),
+           "ranks": dist.get_world_size(), "local_rank_device": [r[:2] for r in rows]}
+    if any(buses):
+        out["pci_bus_ids"] = buses
+        out["distinct_gpus"] = len(set(buses))
+    return out
