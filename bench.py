@@ -31,6 +31,7 @@ tools/bench_legs.py.
 import argparse
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -124,7 +125,8 @@ def main():
     ap.add_argument("--bots", type=int, default=1_000_000, help="bots per arena (the metric is quoted at 10^6)")
     ap.add_argument("--prewarm-ms", type=float, default=100.0,
                     help="device time of scratch work right before every timed leg (clock ramp; never timed); 0 disables")
-    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="time budget of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0,
+                    help="time budget of the cpu_baseline sample on all usable cores (+ a quarter of it on one thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ensemble", action="store_true", help="skip the configs[3] end-to-end run")
     ap.add_argument("--e2e-steps", type=int, default=None, help="bound the timesteps per member of the configs[3] run")
@@ -134,6 +136,7 @@ def main():
     ap.add_argument("--dry-run-device", action="store_true",
                     help="TEST ONLY (tests/test_bench_multirank.py): gloo, no GPU, the arena replaced by a counter")
     args = ap.parse_args()
+    t_start, phases = time.perf_counter(), {}   # (detail record: seconds since start at the end of each phase)
     K.DRY = args.dry_run_device
     K.HEADLINE_VARIANT = 2
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # (the two configs[3] batches must not share a hardware queue)
@@ -154,6 +157,7 @@ def main():
     K.HEADLINE_FORCE_SUMS = 1   # the scratch arena runs the headline's kernel
     warm = K.DevicePrewarm(pb, min(n, 1_000_000), K.LATTICE_PITCH, args.prewarm_ms)
     h = timed_arena(pb, args, rank, world, dist, torch, warm)
+    phases["headline"] = time.perf_counter() - t_start
     wall, summaries, coll = h["wall"], [h["summary"]], None
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device=K.dist_device())
@@ -168,6 +172,7 @@ def main():
     warm.done()
     # (the arenas are closed before the ensemble: with their streams alive the two batches land on one hardware queue)
     ens, ens_detail = (None, None) if args.no_ensemble else configs3_end_to_end(rank, world, dist, torch, args.e2e_steps)
+    phases["ensemble"] = time.perf_counter() - t_start
 
     if rank == 0:
         avg_us = h["dev_ms"] * 1e3 / max(h["launches"], 1)
@@ -201,12 +206,15 @@ def main():
         out["default_form"], detail["default_form"] = default_form_leg(pb, n, min(args.steps, 400),
                                                                        max(args.warmup, 100), warm)
         warm.done()
+        phases["default_form"] = time.perf_counter() - t_start
         if ens is not None:
             out["ensemble"] = ens
         if world == 1 and not args.no_cpu_baseline:
             c = K.cpu_baseline(n, K.LATTICE_PITCH, args.cpu_seconds)
             detail["cpu_baseline"] = c
             out["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "value_1_thread", "kind", "sample")}
+            phases["cpu_baseline"] = time.perf_counter() - t_start
+        detail["phases_end_s"] = phases
         out["detail"] = os.path.relpath(args.detail, ROOT) if args.detail else None
         # the driver reads an 8 KB tail: should the line ever outgrow its budget, the optional blocks go (they are in
         # the detail record), never the contract keys
