@@ -170,8 +170,16 @@ def test_cxx_runner_rendezvous_by_host_name_with_strays_and_foreign_files(tmp_pa
                                PB_RENDEZVOUS_PORT=str(port), PB_LAUNCH_TOKEN="this-launch", **kw)
     rank0 = subprocess.Popen([exe, "--rendezvous-test"], env=env(0), stdout=subprocess.PIPE, text=True)
     time.sleep(0.3)
-    # a stray: right magic, claims to be rank 1, wrong token
-    c = socket.create_connection(("127.0.0.1", port), timeout=5)
+    # a stray: right magic, claims to be rank 1, wrong token  (rank 0 may need longer than 0.3 s to listen on a busy box)
+    deadline = time.time() + 10.0
+    while True:
+        try:
+            c = socket.create_connection(("127.0.0.1", port), timeout=5)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise
+            time.sleep(0.1)
     c.sendall(b"PBID" + (1).to_bytes(4, "little") + bytes(8))
     time.sleep(0.2)
     c.close()
