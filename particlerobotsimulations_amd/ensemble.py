@@ -24,13 +24,16 @@ def shard(n_members, rank, world):
     return list(range(rank, n_members, world))
 
 
-def member_overrides(k, seed0=0, sweep=None):
-    """Override text of member k: its seed, plus one sweep value if `sweep` = (key, values)."""
-    text = f"seed\n{seed0 + k}"
-    if sweep is not None:
-        key, values = sweep
-        text += f"\n{key}\n{values[k % len(values)]}"
-    return text
+def member_overrides(k, seed0=0, sweep=None, cartesian=False):
+    """Override text of member k: its seed, plus one sweep value if `sweep` = (key, values).  cartesian (as
+    `particlebot_ensemble --cartesian`): the values form a grid and every grid point runs under each seed -- member k is
+    grid point k mod G under seed seed0 + k // G -- so the members of one seed share ONE placement."""
+    if sweep is None:
+        return f"seed\n{seed0 + k}"
+    key, values = sweep
+    g = len(values)
+    seed = seed0 + (k // g if cartesian else k)
+    return f"seed\n{seed}\n{key}\n{values[k % g]}"
 
 
 class LocalEnsemble:
@@ -331,6 +334,8 @@ def main():
     ap.add_argument("--seed0", type=int, default=1000)
     ap.add_argument("--set", nargs=2, action="append", default=[], metavar=("NAME", "VALUE"))
     ap.add_argument("--sweep", nargs="+", default=None, metavar="KEY V1 V2 ...")
+    ap.add_argument("--cartesian", action="store_true",
+                    help="with --sweep: every swept value under each seed (member k = value k mod G under seed seed0 + k // G)")
     ap.add_argument("--out", default=None, help="write the gathered summaries (.npy) on rank 0")
     ap.add_argument("--sub-batch", type=int, default=0,
                     help="members per sub-batch of the placement/stepping pipeline (0: all at once; -1: automatic, for "
@@ -358,7 +363,7 @@ def main():
     ids = shard(args.members, rank, world)
     t0 = time.perf_counter()
     # (the same pipeline as bin/particlebot_ensemble: placement overlapped with stepping)
-    e = PipelinedEnsemble(args.cfg, [member_overrides(k, args.seed0, sweep) for k in ids], dict(args.set),
+    e = PipelinedEnsemble(args.cfg, [member_overrides(k, args.seed0, sweep, args.cartesian) for k in ids], dict(args.set),
                           sub_batch=args.sub_batch, host_threads=args.host_threads, csv_dir=args.csv_dir,
                           csv_ids=ids if args.csv_dir else None)
     steps = e.run()

@@ -20,6 +20,9 @@ def test_member_overrides_text():
     from particlerobotsimulations_amd.ensemble import member_overrides
     assert member_overrides(3, seed0=1000) == "seed\n1003"
     assert member_overrides(5, 10, ("nDead", ["0", "10", "20"])) == "seed\n15\nnDead\n20"
+    # cartesian (particlebot_ensemble --cartesian): every value under each seed, value fastest
+    assert [member_overrides(k, 10, ("nDead", ["0", "10", "20"]), cartesian=True) for k in (0, 2, 3, 7)] == [
+        "seed\n10\nnDead\n0", "seed\n10\nnDead\n20", "seed\n11\nnDead\n0", "seed\n12\nnDead\n10"]
 
 
 def _fake_rows(member, rows):
